@@ -1,0 +1,166 @@
+"""ORACLE (test infrastructure, NOT product code) -- torch-CPU restatement of the
+reference hot path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module; the product (``simple-hrnet_amd``) never does.
+
+What it restates (citations into /root/reference):
+  * ``HRNet.forward``            models_/hrnet.py:157-189
+  * ``StageModule.forward``      models_/hrnet.py:55-71  (fuse order j = 0..B-1)
+  * ``Bottleneck.forward``       models_/modules.py:20-40
+  * ``BasicBlock.forward``       models_/modules.py:56-72
+  * heat-map decode loop         SimpleHRNet.py:297-308 (dup. 432-443)
+  * ``max_batch_size`` chunking  SimpleHRNet.py:284-296
+
+The reference's arithmetic lives in PyTorch itself (nn.Conv2d / BatchNorm2d /
+ReLU / Upsample -> ATen -> oneDNN on CPU), so this restatement walks the
+``state_dict`` with the same ``torch.nn.functional`` primitives in the same
+order; on CPU fp32 it reproduces the reference bit-for-bit (pinned by
+tests/test_oracle_vs_reference.py against the real ``models_.hrnet.HRNet`` when
+/root/reference is present, and by the committed fixtures in tests/golden/
+everywhere else).  Parity status: the reference ships no tests or golden
+vectors of its own -- the pin is "outputs of the reference
+itself, run in the build container" (tests/golden/make_golden.py).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+
+
+def _t(sd: Dict, k: str) -> torch.Tensor:
+    v = sd[k]
+    return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
+
+
+def _conv(sd, name, x, stride=1):
+    w = _t(sd, name + ".weight")
+    k = w.shape[-1]
+    b = sd.get(name + ".bias")
+    b = None if b is None else _t(sd, name + ".bias")
+    return F.conv2d(x, w, b, stride=stride, padding=k // 2)
+
+
+def _bn(sd, name, x):
+    # eval-mode BatchNorm2d: y = (x - mean) / sqrt(var + eps) * gamma + beta
+    return F.batch_norm(x, _t(sd, name + ".running_mean"), _t(sd, name + ".running_var"),
+                        _t(sd, name + ".weight"), _t(sd, name + ".bias"), False, 0.0, BN_EPS)
+
+
+def bottleneck(sd, p, x, has_downsample):
+    """modules.py:20-40."""
+    out = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x)))
+    out = F.relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", out)))
+    out = _bn(sd, p + ".bn3", _conv(sd, p + ".conv3", out))
+    res = x
+    if has_downsample:
+        res = _bn(sd, p + ".downsample.1", _conv(sd, p + ".downsample.0", x))
+    return F.relu(out + res)
+
+
+def basic_block(sd, p, x):
+    """modules.py:56-72."""
+    out = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x)))
+    out = _bn(sd, p + ".bn2", _conv(sd, p + ".conv2", out))
+    return F.relu(out + x)
+
+
+def stage_module(sd, p, xs: List[torch.Tensor], nout: int) -> List[torch.Tensor]:
+    """hrnet.py:55-71."""
+    nb = len(xs)
+    ys = []
+    for b in range(nb):
+        y = xs[b]
+        for k in range(4):
+            y = basic_block(sd, "%s.branches.%d.%d" % (p, b, k), y)
+        ys.append(y)
+    fused = []
+    for i in range(nout):
+        acc = None
+        for j in range(nb):
+            q = "%s.fuse_layers.%d.%d" % (p, i, j)
+            if i == j:
+                t = ys[j]
+            elif i < j:  # hrnet.py:30-35
+                t = _bn(sd, q + ".1", _conv(sd, q + ".0", ys[j]))
+                t = F.interpolate(t, scale_factor=float(2 ** (j - i)), mode="nearest")
+            else:  # hrnet.py:36-51
+                t = ys[j]
+                for k in range(i - j - 1):
+                    t = F.relu(_bn(sd, "%s.%d.1" % (q, k), _conv(sd, "%s.%d.0" % (q, k), t, stride=2)))
+                k = i - j - 1
+                t = _bn(sd, "%s.%d.1" % (q, k), _conv(sd, "%s.%d.0" % (q, k), t, stride=2))
+            acc = t if j == 0 else acc + t  # hrnet.py:63-66: left-to-right accumulation
+        fused.append(F.relu(acc))
+    return fused
+
+
+@torch.no_grad()
+def hrnet_forward(sd: Dict, images) -> torch.Tensor:
+    """hrnet.py:157-189.  images: (N,3,H,W) fp32 -> heat-maps (N,J,H/4,W/4)."""
+    x = images if isinstance(images, torch.Tensor) else torch.from_numpy(np.asarray(images))
+    dt = _t(sd, "conv1.weight").dtype
+    x = x.to(dt)
+    x = F.relu(_bn(sd, "bn1", _conv(sd, "conv1", x, stride=2)))
+    x = F.relu(_bn(sd, "bn2", _conv(sd, "conv2", x, stride=2)))
+    for b in range(4):
+        x = bottleneck(sd, "layer1.%d" % b, x, b == 0)
+    xs = [
+        F.relu(_bn(sd, "transition1.0.1", _conv(sd, "transition1.0.0", x))),
+        F.relu(_bn(sd, "transition1.1.0.1", _conv(sd, "transition1.1.0.0", x, stride=2))),
+    ]
+    xs = stage_module(sd, "stage2.0", xs, 2)
+    xs = xs + [F.relu(_bn(sd, "transition2.2.0.1", _conv(sd, "transition2.2.0.0", xs[-1], stride=2)))]
+    for m in range(4):
+        xs = stage_module(sd, "stage3.%d" % m, xs, 3)
+    xs = xs + [F.relu(_bn(sd, "transition3.3.0.1", _conv(sd, "transition3.3.0.0", xs[-1], stride=2)))]
+    xs = stage_module(sd, "stage4.0", xs, 4)
+    xs = stage_module(sd, "stage4.1", xs, 4)
+    xs = stage_module(sd, "stage4.2", xs, 1)
+    return _conv(sd, "final_layer", xs[0])
+
+
+def hrnet_forward_chunked(sd: Dict, images, max_batch_size: int = 32) -> torch.Tensor:
+    """SimpleHRNet.py:284-296: whole batch if it fits, else ``max_batch_size`` slices."""
+    n = len(images)
+    if n <= max_batch_size:
+        return hrnet_forward(sd, images)
+    outs = [hrnet_forward(sd, images[i:i + max_batch_size]) for i in range(0, n, max_batch_size)]
+    return torch.cat(outs, 0)
+
+
+def decode_heatmaps(heatmaps: np.ndarray, boxes: np.ndarray) -> np.ndarray:
+    """SimpleHRNet.py:297-308.  heatmaps (N,J,h,w) fp32 numpy, boxes (N,4)
+    ``[x1,y1,x2,y2]`` int32 (multi-person) or float32 (single-person) ->
+    pts (N,J,3) fp32 ``(y, x, confidence)``.  ``np.argmax`` = first maximum in
+    row-major order; coordinates are evaluated in float64 then stored as fp32."""
+    n, nj, h, w = heatmaps.shape
+    pts = np.empty((n, nj, 3), dtype=np.float32)
+    for i in range(n):
+        for j in range(nj):
+            joint = heatmaps[i, j]
+            pt = np.unravel_index(np.argmax(joint), (h, w))
+            pts[i, j, 0] = pt[0] * 1. / h * (boxes[i][3] - boxes[i][1]) + boxes[i][1]
+            pts[i, j, 1] = pt[1] * 1. / w * (boxes[i][2] - boxes[i][0]) + boxes[i][0]
+            pts[i, j, 2] = joint[pt]
+    return pts
+
+
+def predict_crops(sd: Dict, images, boxes: np.ndarray, max_batch_size: int = 32):
+    """The whole hot path (model call + decode), SimpleHRNet.py:281-308."""
+    out = hrnet_forward_chunked(sd, images, max_batch_size).detach().cpu().numpy()
+    return out, decode_heatmaps(out, boxes)
+
+
+def cast_state_dict(sd: Dict, dtype=torch.float64) -> Dict:
+    """fp64 copy: an independent cross-check of the fp32 oracle's rounding."""
+    out = {}
+    for k, v in sd.items():
+        t = _t(sd, k)
+        out[k] = t.to(dtype) if t.is_floating_point() else t
+    return out

@@ -1,0 +1,159 @@
+"""Deterministic synthetic HRNet checkpoints and crops.
+
+There is no network on the build or GPU boxes, so neither the official
+``pose_hrnet_*.pth`` weights nor real images are available.  Everything that
+needs weights (parity tests, ``bench.py``, ``__graft_entry__.smoke``) uses the
+generator below.  It is *reference-independent*: it enumerates the 1754
+``state_dict`` entries of the reference network by name and shape
+(``/root/reference/models_/hrnet.py:75-155``, ``models_/modules.py:5-72``) and
+fills them from a counter-based numpy RNG, so the very same checkpoint can be
+rebuilt on the GPU box (where ``/root/reference`` does not exist) and loaded
+into the reference ``HRNet`` in the build container
+(``tests/golden/make_golden.py``).
+
+BatchNorm statistics are randomised on purpose: with default-initialised BN the
+fold (``W' = W * g / sqrt(v + eps)``) is numerically invisible, and a folding
+bug would pass every test (SURVEY.md §7 "BN-fold visibility").
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+BN_EPS = 1e-5  # nn.BatchNorm2d default, hrnet.py:80 / modules.py:11
+
+
+def _bn(prefix: str, ch: int) -> List[Tuple[str, Tuple[int, ...], str]]:
+    return [
+        (prefix + ".weight", (ch,), "bn_gamma"),
+        (prefix + ".bias", (ch,), "bn_beta"),
+        (prefix + ".running_mean", (ch,), "bn_mean"),
+        (prefix + ".running_var", (ch,), "bn_var"),
+        (prefix + ".num_batches_tracked", (), "bn_count"),
+    ]
+
+
+def _conv(name: str, cout: int, cin: int, k: int) -> List[Tuple[str, Tuple[int, ...], str]]:
+    return [(name + ".weight", (cout, cin, k, k), "conv")]
+
+
+def hrnet_state_spec(c: int = 48, nof_joints: int = 17) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(key, shape, kind) for every entry of ``HRNet(c, nof_joints).state_dict()``.
+
+    Mirrors the module tree of hrnet.py:75-155 (stem, layer1, transition1-3,
+    stage2-4, final_layer) and hrnet.py:7-53 (StageModule branches + fuse
+    layers).  Verified against the reference in tests/test_synth.py.
+    """
+    s: List[Tuple[str, Tuple[int, ...], str]] = []
+    # stem, hrnet.py:79-83
+    s += _conv("conv1", 64, 3, 3) + _bn("bn1", 64)
+    s += _conv("conv2", 64, 64, 3) + _bn("bn2", 64)
+    # layer1 = 4 x Bottleneck(.., 64), hrnet.py:86-95, modules.py:8-16
+    for b in range(4):
+        cin = 64 if b == 0 else 256
+        p = "layer1.%d" % b
+        s += _conv(p + ".conv1", 64, cin, 1) + _bn(p + ".bn1", 64)
+        s += _conv(p + ".conv2", 64, 64, 3) + _bn(p + ".bn2", 64)
+        s += _conv(p + ".conv3", 256, 64, 1) + _bn(p + ".bn3", 256)
+        if b == 0:
+            s += _conv(p + ".downsample.0", 256, 64, 1) + _bn(p + ".downsample.1", 256)
+    # transition1, hrnet.py:98-109
+    s += _conv("transition1.0.0", c, 256, 3) + _bn("transition1.0.1", c)
+    s += _conv("transition1.1.0.0", 2 * c, 256, 3) + _bn("transition1.1.0.1", 2 * c)
+
+    def stage(name: str, nbranch: int, nout: int) -> None:
+        # StageModule, hrnet.py:7-53
+        for b in range(nbranch):
+            w = c << b
+            for k in range(4):
+                p = "%s.branches.%d.%d" % (name, b, k)
+                s.extend(_conv(p + ".conv1", w, w, 3) + _bn(p + ".bn1", w))
+                s.extend(_conv(p + ".conv2", w, w, 3) + _bn(p + ".bn2", w))
+        for i in range(nout):
+            for j in range(nbranch):
+                p = "%s.fuse_layers.%d.%d" % (name, i, j)
+                if i < j:  # 1x1 conv + BN (+ nearest upsample), hrnet.py:30-35
+                    s.extend(_conv(p + ".0", c << i, c << j, 1) + _bn(p + ".1", c << i))
+                elif i > j:  # chain of 3x3 s2 convs, hrnet.py:36-51
+                    for k in range(i - j - 1):
+                        s.extend(_conv("%s.%d.0" % (p, k), c << j, c << j, 3))
+                        s.extend(_bn("%s.%d.1" % (p, k), c << j))
+                    k = i - j - 1
+                    s.extend(_conv("%s.%d.0" % (p, k), c << i, c << j, 3))
+                    s.extend(_bn("%s.%d.1" % (p, k), c << i))
+
+    stage("stage2.0", 2, 2)  # hrnet.py:112-114
+    s += _conv("transition2.2.0.0", 4 * c, 2 * c, 3) + _bn("transition2.2.0.1", 4 * c)
+    for m in range(4):  # hrnet.py:128-133
+        stage("stage3.%d" % m, 3, 3)
+    s += _conv("transition3.3.0.0", 8 * c, 4 * c, 3) + _bn("transition3.3.0.1", 8 * c)
+    stage("stage4.0", 4, 4)  # hrnet.py:148-152
+    stage("stage4.1", 4, 4)
+    stage("stage4.2", 4, 1)
+    # final_layer: 1x1 conv WITH bias, hrnet.py:155
+    s += [("final_layer.weight", (nof_joints, c, 1, 1), "conv"),
+          ("final_layer.bias", (nof_joints,), "conv_bias")]
+    return s
+
+
+def _rng_for(seed: int, key: str) -> np.random.Generator:
+    # one independent stream per tensor, keyed by name: order-independent
+    return np.random.default_rng([seed, zlib.crc32(key.encode())])
+
+
+def synth_state_dict(c: int = 48, nof_joints: int = 17, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Seeded checkpoint as numpy arrays (fp32; ``num_batches_tracked`` int64).
+
+    conv: U(-b, b), b = 1/sqrt(fan_in)  (the bound torch's default Conv2d init uses)
+    BN:   gamma ~ U(0.5,1.5), beta ~ N(0,0.1), mean ~ N(0,0.1), var ~ U(0.5,1.5)
+    """
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for key, shape, kind in hrnet_state_spec(c, nof_joints):
+        g = _rng_for(seed, key)
+        if kind == "conv":
+            fan_in = shape[1] * shape[2] * shape[3]
+            b = 1.0 / np.sqrt(fan_in)
+            a = g.uniform(-b, b, size=shape)
+        elif kind == "conv_bias":
+            b = 1.0 / np.sqrt(c)
+            a = g.uniform(-b, b, size=shape)
+        elif kind == "bn_gamma":
+            a = g.uniform(0.5, 1.5, size=shape)
+        elif kind in ("bn_beta", "bn_mean"):
+            a = g.normal(0.0, 0.1, size=shape)
+        elif kind == "bn_var":
+            a = g.uniform(0.5, 1.5, size=shape)
+        elif kind == "bn_count":
+            out[key] = np.asarray(1, dtype=np.int64)
+            continue
+        else:  # pragma: no cover
+            raise AssertionError(kind)
+        out[key] = np.ascontiguousarray(a, dtype=np.float32)
+    return out
+
+
+def synth_crops(n: int, height: int, width: int, seed: int = 2) -> np.ndarray:
+    """(n,3,H,W) fp32 crops in the post-normalisation domain (~N(0,1)), the
+    tensor ``SimpleHRNet`` hands to ``self.model`` (SimpleHRNet.py:277-286)."""
+    g = np.random.default_rng([seed, n, height, width])
+    return g.standard_normal((n, 3, height, width), dtype=np.float32)
+
+
+def synth_boxes(n: int, seed: int = 3, frame_hw: Tuple[int, int] = (1080, 1920)) -> np.ndarray:
+    """(n,4) int32 ``[x1,y1,x2,y2]`` person boxes as ``_predict_single`` stores them
+    (SimpleHRNet.py:230,278): may be negative / exceed the frame after padding."""
+    g = np.random.default_rng([seed, n])
+    h = g.integers(300, 900, size=n)
+    w = (h * 3) // 4
+    x1 = g.integers(-50, frame_hw[1] - 100, size=n)
+    y1 = g.integers(-50, frame_hw[0] - 100, size=n)
+    return np.stack([x1, y1, x1 + w, y1 + h], axis=1).astype(np.int32)
+
+
+def to_torch_state_dict(sd: Dict[str, np.ndarray]):
+    import torch
+
+    return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in sd.items())

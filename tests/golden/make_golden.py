@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference; the GPU box has neither
+the reference nor this need -- it consumes the committed *.npz files):
+
+    python tests/golden/make_golden.py
+
+The reference has no tests, weights or golden vectors of its own,
+so the pin for our oracle and for the HIP path is "outputs of the unmodified
+reference code, executed here on CPU fp32, on seeded synthetic weights/inputs":
+
+  * ``models_.hrnet.HRNet`` (hrnet.py:74-189) is imported unmodified and loaded with
+    ``synth_state_dict`` -> heat-map fixtures.
+  * ``SimpleHRNet.predict()`` (SimpleHRNet.py:174-496) is imported unmodified.  Its
+    third-party imports that are absent from this image (cv2, torchvision, the
+    un-vendored YOLOv3 submodule) are replaced by the small stand-ins below, which
+    only touch the pre-path (colour flip, identity-size resize, PIL resize,
+    ToTensor/Normalize) and the detector -- NOT the hot path under test (model call
+    + decode, SimpleHRNet.py:281-308 / 416-443).  The crops the reference hands to
+    ``self.model`` are captured and stored, so the parity tests feed identical bits.
+
+Weights are not stored: they are regenerated from (c, seed) by
+``simple-hrnet_amd/synth.py`` wherever the fixtures are used.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+synth = importlib.import_module("simple-hrnet_amd.synth")
+
+
+# ----------------------------------------------------------------------------- stand-ins (pre-path only)
+def install_stubs():
+    from PIL import Image
+
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_CUBIC = 2
+    cv2.COLOR_BGR2RGB = 4
+
+    def resize(img, dsize, interpolation=None):
+        assert (img.shape[1], img.shape[0]) == tuple(dsize), "stub cv2.resize only supports identity size"
+        return img
+
+    def cvt_color(img, code):
+        assert code == cv2.COLOR_BGR2RGB
+        return np.ascontiguousarray(img[..., ::-1])
+
+    cv2.resize = resize
+    cv2.cvtColor = cvt_color
+    sys.modules["cv2"] = cv2
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToPILImage:
+        def __call__(self, a):
+            return Image.fromarray(np.ascontiguousarray(a))
+
+    class Resize:
+        def __init__(self, size):
+            self.size = size  # (h, w)
+
+        def __call__(self, im):
+            return im.resize((self.size[1], self.size[0]), Image.BILINEAR)
+
+    class ToTensor:
+        def __call__(self, a):
+            a = np.asarray(a)
+            return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).to(torch.float32).div(255)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean = torch.tensor(mean, dtype=torch.float32)[:, None, None]
+            self.std = torch.tensor(std, dtype=torch.float32)[:, None, None]
+
+        def __call__(self, t):
+            return t.sub(self.mean).div(self.std)
+
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    inner = types.ModuleType("torchvision.transforms.transforms")
+    for m in (tvt, inner):
+        m.Compose, m.ToPILImage, m.Resize, m.ToTensor, m.Normalize = Compose, ToPILImage, Resize, ToTensor, Normalize
+    tvt.transforms = inner
+    tv.transforms = tvt
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tvt
+    sys.modules["torchvision.transforms.transforms"] = inner
+
+    # detector stand-in: models_/detectors/YOLOv3.py:79-141 returns, per image, a (P,7) tensor
+    # [x1,y1,x2,y2,conf,cls_conf,cls_pred] or None.
+    det = types.ModuleType("models_.detectors.YOLOv3")
+
+    class YOLOv3:
+        table = {}
+
+        def __init__(self, **kw):
+            pass
+
+        def predict_single(self, image, color_mode="BGR"):
+            return self.predict(np.expand_dims(image, 0))[0]
+
+        def predict(self, images, color_mode="BGR"):
+            return [YOLOv3.table.get(i) for i in range(len(images))]
+
+    det.YOLOv3 = YOLOv3
+    sys.modules["models_.detectors.YOLOv3"] = det
+    return YOLOv3
+
+
+class Capture(torch.nn.Module):
+    """wraps self.model to record what the reference feeds the hot path"""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+        self.inputs = []
+
+    def forward(self, x):
+        self.inputs.append(x.detach().clone())
+        return self.inner(x)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def ref_model(c, seed):
+    from models_.hrnet import HRNet
+
+    m = HRNet(c, 17).eval()
+    m.load_state_dict(synth.to_torch_state_dict(synth.synth_state_dict(c, 17, seed)))
+    return m
+
+
+def ref_decode(out, boxes, h, w):
+    """verbatim behaviour of SimpleHRNet.py:297-308, obtained by running predict() below;
+    for the bare-HRNet fixtures we evaluate the same expressions here."""
+    pts = np.empty((out.shape[0], out.shape[1], 3), dtype=np.float32)
+    for i, human in enumerate(out):
+        for j, joint in enumerate(human):
+            pt = np.unravel_index(np.argmax(joint), (h, w))
+            pts[i, j, 0] = pt[0] * 1. / h * (boxes[i][3] - boxes[i][1]) + boxes[i][1]
+            pts[i, j, 1] = pt[1] * 1. / w * (boxes[i][2] - boxes[i][0]) + boxes[i][0]
+            pts[i, j, 2] = joint[pt]
+    return pts
+
+
+def heatmap_case(name, c, n, h, w, seed=0):
+    m = ref_model(c, seed)
+    x = synth.synth_crops(n, h, w)
+    with torch.no_grad():
+        y = m(torch.from_numpy(x)).numpy()
+    boxes = synth.synth_boxes(n)
+    save(name, c=c, n=n, h=h, w=w, weight_seed=seed, heatmaps=y, boxes=boxes,
+         pts=ref_decode(y, boxes, h // 4, w // 4))
+
+
+def predict_cases(yolo):
+    import SimpleHRNet as S
+
+    tmp = tempfile.mkdtemp()
+
+    def make(c, res, multiperson, seed=0, max_batch_size=32):
+        ck = os.path.join(tmp, "w%d_%d.pth" % (c, seed))
+        torch.save(synth.to_torch_state_dict(synth.synth_state_dict(c, 17, seed)), ck)
+        s = S.SimpleHRNet(c, 17, ck, resolution=res, multiperson=multiperson, return_heatmaps=True,
+                          return_bounding_boxes=True, max_batch_size=max_batch_size, device=torch.device("cpu"))
+        s.model = Capture(s.model)
+        return s
+
+    rng = np.random.default_rng(0)
+
+    # --- config 1 (BASELINE.json configs[0]): W32 256x192, ONE image with 3 people, device='cpu'
+    frame = rng.integers(0, 256, (720, 1280, 3), dtype=np.uint8)
+    yolo.table = {0: torch.tensor([[100.2, 50.7, 400.4, 650.1, .9, .9, 0.],      # tall box -> x padding
+                                   [600.0, 200.0, 1100.0, 500.0, .8, .9, 0.],    # wide box -> y padding
+                                   [-20.0, 300.0, 250.0, 700.0, .7, .9, 0.]])}   # touches the frame edge
+    # (third box starts at x=-20 -> numpy negative-index slicing in the reference, kept as is)
+    yolo.table[0][2, 0] = 5.0
+    s = make(32, (256, 192), True)
+    hm, boxes, pts = s.predict(frame)
+    crops = torch.cat(s.model.inputs, 0).numpy()
+    save("cfg1_w32_256x192_predict_multi", c=32, h=256, w=192, weight_seed=0, crops=crops, boxes=boxes,
+         heatmaps=hm, pts=pts)
+
+    # --- single-person path (float32 boxes, SimpleHRNet.py:213-225), frame == resolution
+    frame = rng.integers(0, 256, (128, 96, 3), dtype=np.uint8)
+    s = make(32, (128, 96), False)
+    hm, boxes, pts = s.predict(frame)
+    save("w32_128x96_predict_single", c=32, h=128, w=96, weight_seed=0, crops=s.model.inputs[0].numpy(),
+         boxes=boxes, heatmaps=hm, pts=pts)
+
+    # --- batch path, single-person, n=5 with max_batch_size=2 -> chunk loop (SimpleHRNet.py:423-429)
+    frames = rng.integers(0, 256, (5, 128, 96, 3), dtype=np.uint8)
+    s = make(48, (128, 96), False, max_batch_size=2)
+    hm, boxes, pts = s.predict(frames)
+    assert len(s.model.inputs) == 3
+    save("w48_128x96_predict_batch5", c=48, h=128, w=96, weight_seed=0,
+         crops=torch.cat(s.model.inputs, 0).numpy(), boxes=boxes, heatmaps=hm, pts=pts)
+
+    # --- batch path, multi-person: image 0 has 2 people, image 1 none, image 2 one
+    frames = rng.integers(0, 256, (3, 480, 640, 3), dtype=np.uint8)
+    yolo.table = {0: torch.tensor([[50., 40., 200., 400., .9, .9, 0.], [300., 100., 620., 300., .9, .9, 0.]]),
+                  1: None,
+                  2: torch.tensor([[10., 10., 630., 470., .9, .9, 0.]])}
+    s = make(32, (128, 96), True)
+    hm, boxes, pts = s.predict(frames)
+    counts = np.array([len(p) for p in pts], dtype=np.int32)
+    save("w32_128x96_predict_batch_multi", c=32, h=128, w=96, weight_seed=0,
+         crops=torch.cat(s.model.inputs, 0).numpy(), counts=counts,
+         boxes=np.concatenate([np.asarray(b, dtype=np.int32).reshape(-1, 4) for b in boxes], 0),
+         heatmaps=np.concatenate(hm, 0), pts=np.concatenate(pts, 0))
+
+
+def main():
+    torch.set_num_threads(os.cpu_count())
+    yolo = install_stubs()
+    heatmap_case("w32_64x64_n2", 32, 2, 64, 64)
+    heatmap_case("w48_64x64_n2", 48, 2, 64, 64)
+    heatmap_case("w32_256x192_n2", 32, 2, 256, 192, seed=1)
+    heatmap_case("w48_384x288_n1", 48, 1, 384, 288)
+    predict_cases(yolo)
+
+
+if __name__ == "__main__":
+    main()
