@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the HRNet hot path (model call + decode, SimpleHRNet.py:281-308) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): person-crops/sec, HRNet-W48 384x288, batch 256 per GPU, bf16 MFMA with fp32
+accumulate, synthetic crops already resident in HBM, random-init (seeded) weights.  One "step" = one pass
+of the hot path over one batch of 256 crops per GPU: stem -> stage1-4 -> head -> arg-max decode ->
+(N>1) all-gather of the keypoints.  N>1: one process per GPU under torch.distributed.run, RCCL backend;
+crops are sharded by contiguous index ranges (weak scaling: 256 crops per GPU), the packed weights are
+broadcast once from rank 0, and the only per-step collective is the all-gather of 204 B/crop of joints.
+
+Prints ONE JSON line on rank 0 (fields per the driver contract, plus `roofline` and `cpu_baseline`).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+PEAK_F32_TFLOPS = 157.3     # fp32 MFMA = vector rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="crops per GPU per step")
+    ap.add_argument("--c", type=int, default=48)
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=288)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--max-batch", type=int, default=int(os.environ.get("HRN_MAX_BATCH", "64")),
+                    help="crops per internal pass (workspace size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, c, h, w, budget_s):
+    """The reference's device='cpu' path restated (oracle/hrnet_torch_oracle.py: same ATen/oneDNN ops the
+    reference dispatches), timed on this box's host cores on a bounded sample of the same workload:
+    batches of `max_batch_size`=32 crops (SimpleHRNet.py:31 default chunking) until the budget is spent."""
+    import torch
+    from oracle import hrnet_torch_oracle as T
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = pkg.synth.to_torch_state_dict(pkg.synth_state_dict(c, 17, 0))
+    chunk = 8
+    crops = torch.from_numpy(pkg.synth_crops(chunk, h, w))
+    boxes = pkg.synth_boxes(chunk)
+    T.predict_crops(sd, crops[:2], boxes[:2])  # warm-up (oneDNN primitive cache)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        T.predict_crops(sd, crops, boxes)
+        done += chunk
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 256:
+            break
+    return {"value": round(done / el, 3), "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": "%d crops (batches of %d) of HRNet-W%d %dx%d fp32, torch-CPU restatement of the reference "
+                      "device='cpu' path incl. decode, %.1f s" % (done, chunk, c, h, w, el)}
+
+
+def main():
+    a = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("simple-hrnet_amd")
+    shard = importlib.import_module("simple-hrnet_amd.dist")
+
+    net = pkg.NativeHRNet(a.c, 17, (a.height, a.width), a.dtype, max_batch=a.max_batch, device=local)
+    eng = shard.ShardedHRNet(net, dist)
+    eng.load_and_broadcast(pkg.synth_state_dict(a.c, 17, 0) if rank == 0 else None, src=0)
+
+    # synthetic crops, device resident (post-normalisation domain ~N(0,1)), different per rank
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn((a.batch, 3, a.height, a.width), generator=g, device=dev, dtype=torch.float32)
+    boxes = torch.from_numpy(pkg.synth_boxes(a.batch, seed=100 + rank)).to(dev)
+
+    def step():
+        return eng.predict_crops_local_then_gather(images, boxes)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pts = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    assert tuple(pts.shape) == (a.batch * world, 17, 3) and bool(torch.isfinite(pts).all())
+
+    out = None
+    if rank == 0:
+        crops_total = a.batch * world * a.steps
+        value = crops_total / el
+        flops = net.flops_per_crop()
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        out = {
+            "metric": "person-crops/sec HRNet-W%d %dx%d (model forward + heat-map decode)" % (a.c, a.height, a.width),
+            "value": round(value, 2), "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "HRNet-W%d %dx%d, batch=%d random crops per GPU, %s MFMA (BASELINE configs[2])"
+                                   % (a.c, a.height, a.width, a.batch, a.dtype),
+                       "global_batch": a.batch * world, "micro_batch": a.max_batch,
+                       "parallelism": "dp%d (crop sharding, RCCL all-gather of keypoints)" % world,
+                       "weights": "random-init seeded (synth_state_dict seed 0), BN stats randomised"},
+            "whole_net_tflops": round(value / world * flops / 1e12, 2),
+            "gflop_per_crop": round(flops / 1e9, 3),
+        }
+        if not a.no_roofline:
+            # per-kernel HIP-event times of one internal pass, same stream as the launches
+            nb = min(a.max_batch, a.batch)
+            for _ in range(2):
+                conv_ms, other = net.profile_pass(images[:nb])
+            infos = net.conv_infos()
+            sub = [(i, ms) for i, ms in zip(infos, conv_ms)
+                   if b".branches." in i.name and (i.name.startswith(b"stage3") or i.name.startswith(b"stage4"))]
+            sub_flops = sum(i.flops for i, _ in sub) * nb
+            sub_ms = sum(ms for _, ms in sub)
+            ach = sub_flops / (sub_ms * 1e-3) / 1e12
+            all_ms = sum(conv_ms) + sum(other.values())
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "conv3x3 s1 (stage-3/4 BasicBlock convs, %d launches)" % len(sub),
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": None,
+                "flops_per_launch": round(sub_flops / len(sub) / 1e9, 3),
+                "avg_launch_ms": round(sub_ms / len(sub), 4),
+                "subset_share_of_pass_time": round(sub_ms / all_ms, 3),
+                "pass_ms": {"convs": round(sum(conv_ms), 3), **{k: round(v, 3) for k, v in other.items()}},
+            }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, a.c, a.height, a.width, a.cpu_seconds)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+/*
+ * hrnet_mi355.h -- C ABI of the MI355X-native HRNet pose-inference hot path.
+ *
+ * This is the drop-in boundary behind SimpleHRNet.predict() of stefanopini/simple-HRNet.
+ * The reference has no native interface on this path: the seam is the Python attribute
+ * `self.model`, invoked as `self.model(images)` (SimpleHRNet.py:284-294, 419-429) and already
+ * swapped for a foreign engine by the reference itself (TRTModule, SimpleHRNet.py:143-147);
+ * the closest native precedent is `void _nms(int*, int*, const float*, int, int, float, int)`
+ * (misc/nms/gpu_nms.hpp:1).  Every entry point below names the reference behaviour it replaces.
+ *
+ * Conventions
+ *   - plain C types only: raw pointers + sizes; no torch / HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*, NULL = the default stream);
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from hrn_last_error() (the reference raises Python exceptions:
+ *     SimpleHRNet.py:107,114,139,210 -- the ctypes shim turns our codes back into them);
+ *   - a handle is bound to one GPU; it is not thread-safe, distinct handles are;
+ *   - all work is stream-ordered on `stream`; nothing allocates inside hrn_forward().
+ */
+#ifndef HRNET_MI355_H
+#define HRNET_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hrn_ctx *hrn_handle;
+
+enum { HRN_F32 = 0, HRN_BF16 = 1 };            /* arithmetic / activation storage type       */
+enum { HRN_BOX_I32 = 0, HRN_BOX_F32 = 1 };     /* boxes dtype: SimpleHRNet.py:230 vs :223      */
+enum { HRN_T_F32 = 0, HRN_T_I64 = 1 };         /* hrn_tensor_desc.dtype                        */
+
+/* One state_dict entry, exactly as `torch.load(checkpoint)` yields it
+ * (SimpleHRNet.py:117-121): name, shape, contiguous host data (conv weights OIHW fp32). */
+typedef struct {
+    const char *name;
+    const void *data;
+    int32_t ndim;
+    int64_t dims[4];
+    int32_t dtype;
+} hrn_tensor_desc;
+
+/* Static description of one convolution of the compiled graph (for tests / tooling). */
+typedef struct {
+    char name[96];        /* state_dict prefix of the conv, e.g. "stage3.1.branches.2.0.conv1" */
+    int32_t cin, cout, ksize, stride, relu, has_residual;
+    int32_t in_h, in_w, out_h, out_w;
+    int32_t kpad;         /* K = ksize*ksize*cin rounded up to the MFMA K-chunk                 */
+    int32_t nr;           /* 16-wide cout fragments per group (packing parameter)              */
+    int64_t w_offset;     /* byte offset of the packed weights in the blob                     */
+    int64_t w_bytes;
+    int64_t b_offset;     /* byte offset of the folded fp32 bias                                */
+    double flops;         /* 2*MAC per crop                                                    */
+} hrn_conv_info;
+
+/* Replaces `HRNet(c, nof_joints)` + `.to(device).eval()` (SimpleHRNet.py:110,141-142; graph of
+ * models_/hrnet.py:75-155).  height/width = network input resolution (multiples of 32),
+ * max_batch = largest micro-batch one internal pass will process (workspace is sized for it;
+ * hrn_forward accepts any n and chunks internally like SimpleHRNet.py:285-294).
+ * device_id >= 0: HIP device.  device_id < 0: plan-only handle (no GPU touched; graph,
+ * folding and packing run on the host so the host logic is testable on a CPU-only box;
+ * hrn_forward fails on such a handle -- there is NO CPU compute path). */
+int hrn_create(hrn_handle *out, int c, int nof_joints, int height, int width, int dtype, int max_batch,
+               int device_id);
+void hrn_destroy(hrn_handle h);
+const char *hrn_last_error(hrn_handle h); /* h may be NULL: error of the last failed hrn_create */
+
+/* Replaces `model.load_state_dict(checkpoint)` (SimpleHRNet.py:117-121).  Folds every
+ * (conv, BatchNorm) pair (eps 1e-5), repacks to the MFMA fragment layout and uploads. */
+int hrn_load_weights(hrn_handle h, const hrn_tensor_desc *descs, int n);
+
+/* Multi-GPU weight distribution (replaces DataParallel's per-forward `replicate`,
+ * SimpleHRNet.py:135): the packed blob is one contiguous device buffer that rank 0 fills via
+ * hrn_load_weights and the other ranks receive by ONE RCCL broadcast, then adopt. */
+int64_t hrn_weight_blob_bytes(hrn_handle h);
+void *hrn_weight_blob_ptr(hrn_handle h);            /* device pointer (host pointer if plan-only) */
+int hrn_adopt_weights(hrn_handle h);                /* mark an externally filled blob as loaded   */
+int hrn_weight_blob_read(hrn_handle h, int64_t offset, void *dst_host, int64_t nbytes);
+
+/* Replaces the model call + decode loop, SimpleHRNet.py:281-308 (dup. 416-443):
+ *   images_dev  (n,3,H,W) fp32 NCHW device pointer -- what SimpleHRNet hands to self.model
+ *   boxes_dev   (n,4) [x1,y1,x2,y2] device pointer, int32 or fp32 per box_dtype; may be NULL
+ *               when pts_dev is NULL
+ *   pts_dev     (n,joints,3) fp32 device pointer (y, x, confidence) or NULL
+ *   heatmaps_dev (n,joints,H/4,W/4) fp32 NCHW device pointer or NULL (return_heatmaps,
+ *               and the level-1 "self.model(images)" seam)
+ * At least one of pts_dev / heatmaps_dev must be non-NULL. */
+int hrn_forward(hrn_handle h, const void *images_dev, int n, const void *boxes_dev, int box_dtype, float *pts_dev,
+                float *heatmaps_dev, void *stream);
+
+/* Introspection used by tests, bench.py and the roofline accounting. */
+int hrn_conv_count(hrn_handle h);
+int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out);
+double hrn_flops_per_crop(hrn_handle h);            /* 2*MAC, convolutions only              */
+int64_t hrn_workspace_bytes(hrn_handle h);
+int hrn_launches_per_pass(hrn_handle h);
+/* per-kernel HIP-event timing of one pass (dominant-kernel roofline in bench.py):
+ * runs one micro-batch of n crops and returns, for conv i, its device time in ms. */
+int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms, int conv_ms_len,
+                     float *other_ms /* [4]: stem, fuse, head, decode */, void *stream);
+const char *hrn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRNET_MI355_H */

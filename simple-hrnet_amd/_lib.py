@@ -1,0 +1,113 @@
+"""ctypes binding of ``libhrnet_mi355.so`` (C ABI in ``include/hrnet_mi355.h``) and its build recipe.
+
+The library is compiled in-tree with ``hipcc --offload-arch=gfx950`` (cross-compiles without a GPU);
+the resulting ``.so`` is git-ignored but travels to the GPU box with the repo snapshot.
+There is deliberately no fallback: if the library cannot be built or loaded, importing users fail.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+from typing import List
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+LIB_PATH = os.path.join(_HERE, "libhrnet_mi355.so")
+SOURCES = ["kernels.hip", "hrnet_mi355.cpp"]
+HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(INCLUDE, "hrnet_mi355.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X HRNet library cannot be built")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source of the package for gfx950 into ``libhrnet_mi355.so``."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+class TensorDesc(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.c_void_p), ("ndim", ctypes.c_int32),
+                ("dims", ctypes.c_int64 * 4), ("dtype", ctypes.c_int32)]
+
+
+class ConvInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 96),
+                ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("ksize", ctypes.c_int32),
+                ("stride", ctypes.c_int32), ("relu", ctypes.c_int32), ("has_residual", ctypes.c_int32),
+                ("in_h", ctypes.c_int32), ("in_w", ctypes.c_int32), ("out_h", ctypes.c_int32),
+                ("out_w", ctypes.c_int32), ("kpad", ctypes.c_int32), ("nr", ctypes.c_int32),
+                ("w_offset", ctypes.c_int64), ("w_bytes", ctypes.c_int64), ("b_offset", ctypes.c_int64),
+                ("flops", ctypes.c_double)]
+
+
+# every symbol include/hrnet_mi355.h declares: (restype, argtypes)
+_P = ctypes.c_void_p
+SYMBOLS = {
+    "hrn_create": (ctypes.c_int, [ctypes.POINTER(_P), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "hrn_destroy": (None, [_P]),
+    "hrn_last_error": (ctypes.c_char_p, [_P]),
+    "hrn_load_weights": (ctypes.c_int, [_P, ctypes.POINTER(TensorDesc), ctypes.c_int]),
+    "hrn_weight_blob_bytes": (ctypes.c_int64, [_P]),
+    "hrn_weight_blob_ptr": (_P, [_P]),
+    "hrn_adopt_weights": (ctypes.c_int, [_P]),
+    "hrn_weight_blob_read": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int64]),
+    "hrn_forward": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P]),
+    "hrn_conv_count": (ctypes.c_int, [_P]),
+    "hrn_get_conv_info": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ConvInfo)]),
+    "hrn_flops_per_crop": (ctypes.c_double, [_P]),
+    "hrn_workspace_bytes": (ctypes.c_int64, [_P]),
+    "hrn_launches_per_pass": (ctypes.c_int, [_P]),
+    "hrn_profile_pass": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_float), _P]),
+    "hrn_version": (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+def load(auto_build: bool = True) -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if auto_build and needs_build():
+        build()
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library diverge
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def header_symbols() -> List[str]:
+    """names of the functions declared in include/hrnet_mi355.h (parsed, for the export test)"""
+    import re
+
+    text = open(os.path.join(INCLUDE, "hrnet_mi355.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hrn_[a-z_0-9]+)\s*\(", text)))

@@ -1,0 +1,696 @@
+// Host runtime of the MI355X-native HRNet hot path: graph compiler (static launch list for a given
+// width c / resolution), BatchNorm folding + MFMA-fragment weight packing, workspace planner and the
+// C ABI declared in include/hrnet_mi355.h.  Graph follows models_/hrnet.py:157-189 (HRNet.forward),
+// :55-71 (StageModule.forward) and models_/modules.py:20-40,56-72 of the reference.
+#include "../../include/hrnet_mi355.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+using namespace hrn;
+
+std::string g_create_error;
+
+struct Tensor {
+    int c = 0, h = 0, w = 0;
+    int wp = 0, hp = 0, hpwp = 0;
+    int buf = -1;
+};
+
+struct Buffer {
+    int c, h, w;
+    size_t lead_rows, rows, bytes;
+    char *dev = nullptr;  // allocation start
+    bool in_use = false;
+};
+
+enum OpKind { OP_STEM, OP_CONV, OP_FUSE, OP_HEAD, OP_DECODE };
+
+struct ConvOp {
+    std::string conv, bn;  // state_dict prefixes ("" bn => plain bias conv)
+    int in_t, out_t, res_t;
+    int cin, cout, k, stride, relu;
+    int kpad, kchunks, nr;
+    int64_t w_off = 0, w_bytes = 0, b_off = 0;
+    double flops = 0;
+};
+
+struct FuseOp {
+    int term_t[4];
+    int shift[4];
+    int nterms;
+    int out_t;
+};
+
+struct Op {
+    OpKind kind;
+    int idx;  // index into convs / fuses
+};
+
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+}  // namespace
+
+struct hrn_ctx {
+    int c, joints, H, W, dtype, max_batch, device;
+    bool plan_only;
+    int esize;
+    std::string err;
+
+    std::vector<Tensor> tensors;
+    std::vector<Buffer> buffers;
+    std::vector<ConvOp> convs;
+    std::vector<FuseOp> fuses;
+    std::vector<Op> ops;
+    int stem_out_t = -1, head_in_t = -1;
+    int64_t stem_w_off = 0, stem_b_off = 0, head_w_off = 0, head_b_off = 0;
+
+    int64_t blob_bytes = 0;
+    char *blob = nullptr;  // device (or host when plan_only)
+    bool weights_loaded = false;
+
+    int head_slabs = 1, head_slab_px = 1024;
+    float *part_val = nullptr;
+    int *part_idx = nullptr;
+    int64_t workspace_bytes = 0;
+
+    // ---------------------------------------------------------------- planning
+    int new_tensor(int ch, int h, int w) {
+        Tensor t;
+        t.c = ch, t.h = h, t.w = w, t.wp = w + 1, t.hp = h + 1, t.hpwp = t.wp * t.hp;
+        for (size_t i = 0; i < buffers.size(); ++i)
+            if (!buffers[i].in_use && buffers[i].c == ch && buffers[i].h == h && buffers[i].w == w) {
+                t.buf = (int)i;
+                break;
+            }
+        if (t.buf < 0) {
+            Buffer b;
+            b.c = ch, b.h = h, b.w = w;
+            b.lead_rows = (size_t)t.wp + 1;
+            // image rows + bottom halo + one conv block of overrun (masked lanes still form addresses)
+            b.rows = b.lead_rows + (size_t)max_batch * t.hpwp + t.wp + 1 + kConvBlockRows;
+            b.bytes = (size_t)align_up((int64_t)(b.rows * ch * esize), 256);
+            buffers.push_back(b);
+            t.buf = (int)buffers.size() - 1;
+        }
+        buffers[t.buf].in_use = true;
+        tensors.push_back(t);
+        return (int)tensors.size() - 1;
+    }
+    void release(int t) { buffers[tensors[t].buf].in_use = false; }
+
+    int add_conv(const std::string &conv, const std::string &bn, int in_t, int cout, int k, int stride, int relu,
+                 int res_t = -1) {
+        const Tensor &ti = tensors[in_t];
+        ConvOp op;
+        op.conv = conv, op.bn = bn, op.in_t = in_t, op.res_t = res_t;
+        op.cin = ti.c, op.cout = cout, op.k = k, op.stride = stride, op.relu = relu;
+        const int oh = ti.h / stride, ow = ti.w / stride;
+        op.out_t = new_tensor(cout, oh, ow);
+        const int kc = dtype == HRN_BF16 ? 32 : 16;
+        const int K = k * k * op.cin;
+        op.kchunks = (K + kc - 1) / kc;
+        op.kpad = op.kchunks * kc;
+        op.nr = (cout % 64 == 0) ? 4 : (cout % 48 == 0) ? 3 : 2;
+        op.flops = 2.0 * cout * (double)K * oh * ow;
+        convs.push_back(op);
+        ops.push_back({OP_CONV, (int)convs.size() - 1});
+        return op.out_t;
+    }
+
+    int add_fuse(const std::vector<int> &terms, const std::vector<int> &shifts) {
+        FuseOp f;
+        f.nterms = (int)terms.size();
+        for (int i = 0; i < f.nterms; ++i) f.term_t[i] = terms[i], f.shift[i] = shifts[i];
+        const Tensor &t0 = tensors[terms[0]];
+        // output geometry = geometry of a shift-0 term
+        int ref = -1;
+        for (int i = 0; i < f.nterms; ++i)
+            if (shifts[i] == 0) ref = terms[i];
+        const Tensor &tr = tensors[ref >= 0 ? ref : terms[0]];
+        (void)t0;
+        f.out_t = new_tensor(tr.c, tr.h, tr.w);
+        fuses.push_back(f);
+        ops.push_back({OP_FUSE, (int)fuses.size() - 1});
+        return f.out_t;
+    }
+
+    // StageModule, hrnet.py:7-71
+    void add_stage(const std::string &name, std::vector<int> &xs, int nout) {
+        const int nb = (int)xs.size();
+        char buf[160];
+        for (int b = 0; b < nb; ++b) {
+            const int w = c << b;
+            for (int k = 0; k < 4; ++k) {  // BasicBlock, modules.py:56-72
+                snprintf(buf, sizeof buf, "%s.branches.%d.%d", name.c_str(), b, k);
+                const std::string p = buf;
+                const int t1 = add_conv(p + ".conv1", p + ".bn1", xs[b], w, 3, 1, 1);
+                const int t2 = add_conv(p + ".conv2", p + ".bn2", t1, w, 3, 1, 1, xs[b]);
+                release(t1);
+                release(xs[b]);
+                xs[b] = t2;
+            }
+        }
+        std::vector<int> outs;
+        for (int i = 0; i < nout; ++i) {
+            std::vector<int> terms, shifts, temps;
+            for (int j = 0; j < nb; ++j) {
+                snprintf(buf, sizeof buf, "%s.fuse_layers.%d.%d", name.c_str(), i, j);
+                const std::string q = buf;
+                if (i == j) {
+                    terms.push_back(xs[j]), shifts.push_back(0);
+                } else if (i < j) {  // 1x1 conv + BN, upsample folded into the fuse read (hrnet.py:30-35)
+                    const int lo = add_conv(q + ".0", q + ".1", xs[j], c << i, 1, 1, 0);
+                    terms.push_back(lo), shifts.push_back(j - i), temps.push_back(lo);
+                } else {  // chain of 3x3 s2 convs (hrnet.py:36-51)
+                    int t = xs[j];
+                    for (int k = 0; k < i - j; ++k) {
+                        const bool last = (k == i - j - 1);
+                        snprintf(buf, sizeof buf, "%s.%d", q.c_str(), k);
+                        const std::string qq = buf;
+                        const int nt = add_conv(qq + ".0", qq + ".1", t, last ? (c << i) : (c << j), 3, 2, last ? 0 : 1);
+                        if (t != xs[j]) release(t);
+                        t = nt;
+                    }
+                    terms.push_back(t), shifts.push_back(0), temps.push_back(t);
+                }
+            }
+            outs.push_back(add_fuse(terms, shifts));
+            for (int t : temps) release(t);
+        }
+        for (int b = 0; b < nb; ++b) release(xs[b]);
+        xs = outs;
+    }
+
+    void build_plan() {
+        const int kc_dummy = 0;
+        (void)kc_dummy;
+        // stem conv1 (dedicated kernel), hrnet.py:158-160
+        stem_out_t = new_tensor(64, H / 2, W / 2);
+        ops.push_back({OP_STEM, 0});
+        int x = add_conv("conv2", "bn2", stem_out_t, 64, 3, 2, 1);  // hrnet.py:161-163
+        release(stem_out_t);
+        char buf[96];
+        for (int b = 0; b < 4; ++b) {  // layer1: Bottleneck x4, modules.py:20-40
+            snprintf(buf, sizeof buf, "layer1.%d", b);
+            const std::string p = buf;
+            const int o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1);
+            const int o2 = add_conv(p + ".conv2", p + ".bn2", o1, 64, 3, 1, 1);
+            int r = x;
+            if (b == 0) r = add_conv(p + ".downsample.0", p + ".downsample.1", x, 256, 1, 1, 0);
+            const int o3 = add_conv(p + ".conv3", p + ".bn3", o2, 256, 1, 1, 1, r);
+            release(o1), release(o2);
+            if (b == 0) release(r);
+            release(x);
+            x = o3;
+        }
+        std::vector<int> xs;
+        xs.push_back(add_conv("transition1.0.0", "transition1.0.1", x, c, 3, 1, 1));
+        xs.push_back(add_conv("transition1.1.0.0", "transition1.1.0.1", x, 2 * c, 3, 2, 1));
+        release(x);
+        add_stage("stage2.0", xs, 2);
+        xs.push_back(add_conv("transition2.2.0.0", "transition2.2.0.1", xs[1], 4 * c, 3, 2, 1));
+        for (int m = 0; m < 4; ++m) {
+            snprintf(buf, sizeof buf, "stage3.%d", m);
+            add_stage(buf, xs, 3);
+        }
+        xs.push_back(add_conv("transition3.3.0.0", "transition3.3.0.1", xs[2], 8 * c, 3, 2, 1));
+        add_stage("stage4.0", xs, 4);
+        add_stage("stage4.1", xs, 4);
+        add_stage("stage4.2", xs, 1);
+        head_in_t = xs[0];
+        ops.push_back({OP_HEAD, 0});
+        ops.push_back({OP_DECODE, 0});
+
+        // weight blob layout
+        int64_t off = 0;
+        stem_w_off = off, off = align_up(off + 27 * 64 * 4, 256);
+        stem_b_off = off, off = align_up(off + 64 * 4, 256);
+        for (auto &cv : convs) {
+            cv.w_off = off;
+            cv.w_bytes = (int64_t)(cv.cout / 16) * cv.kchunks * 1024;
+            off = align_up(off + cv.w_bytes, 256);
+            cv.b_off = off;
+            off = align_up(off + cv.cout * 4, 256);
+        }
+        head_w_off = off, off = align_up(off + (int64_t)joints * c * 4, 256);
+        head_b_off = off, off = align_up(off + joints * 4, 256);
+        blob_bytes = off;
+
+        const int hw = (H / 4) * (W / 4);
+        head_slab_px = 1024;
+        head_slabs = (hw + head_slab_px - 1) / head_slab_px;
+    }
+
+    // ---------------------------------------------------------------- device memory
+    bool hip_ok(hipError_t e, const char *what) {
+        if (e == hipSuccess) return true;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return false;
+    }
+
+    bool allocate() {
+        workspace_bytes = 0;
+        for (auto &b : buffers) workspace_bytes += (int64_t)b.bytes;
+        const int64_t part = (int64_t)max_batch * joints * head_slabs;
+        workspace_bytes += part * 8;
+        if (plan_only) {
+            blob = (char *)calloc(1, (size_t)blob_bytes);
+            return blob != nullptr;
+        }
+        if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return false;
+        for (auto &b : buffers) {
+            if (!hip_ok(hipMalloc((void **)&b.dev, b.bytes), "hipMalloc(activation)")) return false;
+            if (!hip_ok(hipMemset(b.dev, 0, b.bytes), "hipMemset(activation)")) return false;
+        }
+        if (!hip_ok(hipMalloc((void **)&blob, (size_t)blob_bytes), "hipMalloc(weights)")) return false;
+        if (!hip_ok(hipMemset(blob, 0, (size_t)blob_bytes), "hipMemset(weights)")) return false;
+        if (!hip_ok(hipMalloc((void **)&part_val, (size_t)part * 4), "hipMalloc(part_val)")) return false;
+        if (!hip_ok(hipMalloc((void **)&part_idx, (size_t)part * 4), "hipMalloc(part_idx)")) return false;
+        return hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    }
+
+    void free_all() {
+        if (plan_only) {
+            free(blob);
+        } else {
+            (void)hipSetDevice(device);
+            for (auto &b : buffers)
+                if (b.dev) (void)hipFree(b.dev);
+            if (blob) (void)hipFree(blob);
+            if (part_val) (void)hipFree(part_val);
+            if (part_idx) (void)hipFree(part_idx);
+        }
+        blob = nullptr;
+    }
+
+    char *row0(int t) const {
+        const Tensor &tt = tensors[t];
+        const Buffer &b = buffers[tt.buf];
+        return b.dev ? b.dev + b.lead_rows * tt.c * esize : nullptr;
+    }
+
+    // ---------------------------------------------------------------- weights
+    struct Src {
+        const float *p = nullptr;
+        int64_t count = 0;
+    };
+
+    bool lookup(const std::map<std::string, Src> &m, const std::string &key, int64_t expect, const float **out) {
+        auto it = m.find(key);
+        if (it == m.end()) {
+            err = "state_dict is missing key '" + key + "'";
+            return false;
+        }
+        if (it->second.count != expect) {
+            err = "state_dict key '" + key + "' has " + std::to_string(it->second.count) + " elements, expected " +
+                  std::to_string(expect);
+            return false;
+        }
+        *out = it->second.p;
+        return true;
+    }
+
+    // scale/shift of an eval-mode BatchNorm2d (eps 1e-5): y = x*scale + shift
+    bool bn_fold(const std::map<std::string, Src> &m, const std::string &bn, int ch, std::vector<double> &scale,
+                 std::vector<double> &shift) {
+        const float *g, *b, *mu, *var;
+        if (!lookup(m, bn + ".weight", ch, &g) || !lookup(m, bn + ".bias", ch, &b) ||
+            !lookup(m, bn + ".running_mean", ch, &mu) || !lookup(m, bn + ".running_var", ch, &var))
+            return false;
+        scale.resize(ch), shift.resize(ch);
+        for (int i = 0; i < ch; ++i) {
+            scale[i] = (double)g[i] / std::sqrt((double)var[i] + 1e-5);
+            shift[i] = (double)b[i] - (double)mu[i] * scale[i];
+        }
+        return true;
+    }
+
+    bool load_weights(const hrn_tensor_desc *descs, int n) {
+        std::map<std::string, Src> m;
+        for (int i = 0; i < n; ++i) {
+            if (descs[i].dtype != HRN_T_F32 || !descs[i].data || !descs[i].name) continue;
+            int64_t cnt = 1;
+            for (int d = 0; d < descs[i].ndim; ++d) cnt *= descs[i].dims[d];
+            m[descs[i].name] = Src{(const float *)descs[i].data, cnt};
+        }
+        std::vector<char> host((size_t)blob_bytes, 0);
+        std::vector<double> scale, shift;
+        // stem: w[k = ci*9+kh*3+kw][co]
+        {
+            const float *w;
+            if (!lookup(m, "conv1.weight", 64 * 27, &w) || !bn_fold(m, "bn1", 64, scale, shift)) return false;
+            float *dw = (float *)(host.data() + stem_w_off), *db = (float *)(host.data() + stem_b_off);
+            for (int co = 0; co < 64; ++co) {
+                for (int k = 0; k < 27; ++k) dw[k * 64 + co] = (float)((double)w[co * 27 + k] * scale[co]);
+                db[co] = (float)shift[co];
+            }
+        }
+        std::vector<float> wf;
+        for (auto &cv : convs) {
+            const float *w;
+            const int kk = cv.k * cv.k, K = kk * cv.cin;
+            if (!lookup(m, cv.conv + ".weight", (int64_t)cv.cout * K, &w) ||
+                !bn_fold(m, cv.bn, cv.cout, scale, shift))
+                return false;
+            // fold + reorder OIHW -> [co][tap*cin + ci]
+            wf.assign((size_t)cv.cout * K, 0.f);
+            for (int co = 0; co < cv.cout; ++co)
+                for (int ci = 0; ci < cv.cin; ++ci)
+                    for (int t = 0; t < kk; ++t)
+                        wf[(size_t)co * K + t * cv.cin + ci] =
+                            (float)((double)w[((size_t)co * cv.cin + ci) * kk + t] * scale[co]);
+            pack_conv(cv, wf.data(), K, host.data() + cv.w_off);
+            float *db = (float *)(host.data() + cv.b_off);
+            for (int co = 0; co < cv.cout; ++co) db[co] = (float)shift[co];
+        }
+        {
+            const float *w, *b;
+            if (!lookup(m, "final_layer.weight", (int64_t)joints * c, &w) || !lookup(m, "final_layer.bias", joints, &b))
+                return false;
+            memcpy(host.data() + head_w_off, w, sizeof(float) * joints * c);
+            memcpy(host.data() + head_b_off, b, sizeof(float) * joints);
+        }
+        if (plan_only) {
+            memcpy(blob, host.data(), (size_t)blob_bytes);
+        } else {
+            if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return false;
+            if (!hip_ok(hipMemcpy(blob, host.data(), (size_t)blob_bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)"))
+                return false;
+        }
+        weights_loaded = true;
+        return true;
+    }
+
+    // Fragment-major packing.  One fragment = 16 packed rows x one K-chunk = 64 lanes x 16 B,
+    // stored lane-linear so a wave loads it with one coalesced 1 KiB access.  Fragment f = ng*NR + j holds,
+    // in packed row i (= lane & 15), output channel  ng*16*NR + (i>>2)*4*NR + j*4 + (i&3); lane group
+    // g = lane>>4 holds k = kc*KC + g*VEC + [0,VEC).  With the operand swap D = W * X^T each lane then owns
+    // 4*NR contiguous channels of one pixel.
+    void pack_conv(const ConvOp &cv, const float *wf, int K, char *dst) const {
+        const int KC = dtype == HRN_BF16 ? 32 : 16, VEC = dtype == HRN_BF16 ? 8 : 4;
+        const int nfrag = cv.cout / 16;
+        for (int f = 0; f < nfrag; ++f) {
+            const int ng = f / cv.nr, j = f % cv.nr;
+            for (int kc = 0; kc < cv.kchunks; ++kc)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int li = lane & 15, g = lane >> 4;
+                    const int co = ng * 16 * cv.nr + (li >> 2) * 4 * cv.nr + j * 4 + (li & 3);
+                    char *d = dst + (((size_t)f * cv.kchunks + kc) * 64 + lane) * 16;
+                    for (int e = 0; e < VEC; ++e) {
+                        const int k = kc * KC + g * VEC + e;
+                        const float v = k < K ? wf[(size_t)co * K + k] : 0.f;
+                        if (dtype == HRN_BF16)
+                            ((uint16_t *)d)[e] = f32_to_bf16_host(v);
+                        else
+                            ((float *)d)[e] = v;
+                    }
+                }
+        }
+    }
+
+    // ---------------------------------------------------------------- execution
+    struct Timing {
+        std::vector<hipEvent_t> ev;  // ops.size()+1 events
+    };
+
+    bool run_pass(const float *images, int nb, const void *boxes, int box_dtype, float *pts, float *heatmaps,
+                  hipStream_t s, Timing *tm) {
+        if (tm && !hip_ok(hipEventRecord(tm->ev[0], s), "hipEventRecord")) return false;
+        for (size_t oi = 0; oi < ops.size(); ++oi) {
+            const Op &op = ops[oi];
+            hipError_t e = hipSuccess;
+            switch (op.kind) {
+                case OP_STEM: {
+                    const Tensor &t = tensors[stem_out_t];
+                    StemArgs a;
+                    a.images = images, a.out = row0(stem_out_t);
+                    a.w = (const float *)(blob + stem_w_off), a.bias = (const float *)(blob + stem_b_off);
+                    a.n = nb, a.H = H, a.W = W;
+                    a.out_h = t.h, a.out_w = t.w, a.out_wp = t.wp, a.out_hpwp = t.hpwp;
+                    e = launch_stem(dtype, a, s);
+                    break;
+                }
+                case OP_CONV: {
+                    const ConvOp &cv = convs[op.idx];
+                    const Tensor &ti = tensors[cv.in_t], &to = tensors[cv.out_t];
+                    ConvArgs a;
+                    a.in = row0(cv.in_t), a.out = row0(cv.out_t);
+                    a.w = blob + cv.w_off, a.bias = (const float *)(blob + cv.b_off);
+                    a.res = cv.res_t >= 0 ? row0(cv.res_t) : nullptr;
+                    a.cin = cv.cin, a.cout = cv.cout;
+                    a.in_wp = ti.wp, a.in_hpwp = ti.hpwp;
+                    a.out_h = to.h, a.out_w = to.w, a.out_wp = to.wp, a.out_hpwp = to.hpwp;
+                    a.m = nb * to.hpwp;
+                    a.ksize = cv.k, a.stride = cv.stride, a.relu = cv.relu, a.kchunks = cv.kchunks;
+                    e = launch_conv(dtype, a, cv.nr, s);
+                    break;
+                }
+                case OP_FUSE: {
+                    const FuseOp &f = fuses[op.idx];
+                    const Tensor &to = tensors[f.out_t];
+                    FuseArgs a;
+                    a.nterms = f.nterms;
+                    for (int i = 0; i < f.nterms; ++i) {
+                        const Tensor &tt = tensors[f.term_t[i]];
+                        a.t[i].ptr = row0(f.term_t[i]), a.t[i].shift = f.shift[i];
+                        a.t[i].wp = tt.wp, a.t[i].hpwp = tt.hpwp;
+                    }
+                    for (int i = f.nterms; i < 4; ++i) a.t[i] = FuseTerm{nullptr, 0, 0, 0};
+                    a.out = row0(f.out_t), a.c = to.c, a.h = to.h, a.w = to.w, a.wp = to.wp, a.hpwp = to.hpwp;
+                    a.m = nb * to.hpwp;
+                    e = launch_fuse(dtype, a, s);
+                    break;
+                }
+                case OP_HEAD: {
+                    const Tensor &t = tensors[head_in_t];
+                    HeadArgs a;
+                    a.in = row0(head_in_t);
+                    a.wgt = (const float *)(blob + head_w_off), a.bias = (const float *)(blob + head_b_off);
+                    a.heatmaps = heatmaps, a.part_val = part_val, a.part_idx = part_idx;
+                    a.n = nb, a.c = t.c, a.joints = joints, a.h = t.h, a.w = t.w, a.wp = t.wp, a.hpwp = t.hpwp;
+                    a.slabs = head_slabs, a.slab_px = head_slab_px;
+                    e = launch_head(dtype, a, s);
+                    break;
+                }
+                case OP_DECODE: {
+                    if (!pts) break;
+                    const Tensor &t = tensors[head_in_t];
+                    DecodeArgs a;
+                    a.part_val = part_val, a.part_idx = part_idx, a.boxes = boxes;
+                    a.box_is_float = box_dtype == HRN_BOX_F32, a.pts = pts;
+                    a.n = nb, a.joints = joints, a.h = t.h, a.w = t.w, a.slabs = head_slabs;
+                    e = launch_decode(a, s);
+                    break;
+                }
+            }
+            if (!hip_ok(e, "kernel launch")) return false;
+            if (tm && !hip_ok(hipEventRecord(tm->ev[oi + 1], s), "hipEventRecord")) return false;
+        }
+        return true;
+    }
+
+    bool check_forward_args(const void *images, int n, const void *boxes, float *pts, float *heatmaps) {
+        if (plan_only) {
+            err = "plan-only handle (device_id < 0): there is no CPU compute path";
+            return false;
+        }
+        if (!weights_loaded) {
+            err = "weights not loaded (call hrn_load_weights or hrn_adopt_weights)";
+            return false;
+        }
+        if (n < 0 || (n > 0 && !images)) {
+            err = "bad images / n";
+            return false;
+        }
+        if (!pts && !heatmaps) {
+            err = "both pts and heatmaps are NULL";
+            return false;
+        }
+        if (pts && !boxes && n > 0) {
+            err = "pts requested without boxes";
+            return false;
+        }
+        return true;
+    }
+};
+
+// ====================================================================================================
+extern "C" {
+
+const char *hrn_version(void) { return "hrnet_mi355 0.1 (gfx950)"; }
+
+int hrn_create(hrn_handle *out, int c, int nof_joints, int height, int width, int dtype, int max_batch,
+               int device_id) {
+    if (!out) return 1;
+    *out = nullptr;
+    if (c < 16 || c % 16 != 0) {
+        g_create_error = "c must be a positive multiple of 16 (HRNet-W32 / W48)";
+        return 2;
+    }
+    if (height <= 0 || width <= 0 || height % 32 || width % 32) {
+        g_create_error = "resolution must be a positive multiple of 32 in both dimensions";
+        return 2;
+    }
+    if (nof_joints <= 0 || nof_joints > 32) {
+        g_create_error = "nof_joints must be in [1, 32]";
+        return 2;
+    }
+    if (dtype != HRN_F32 && dtype != HRN_BF16) {
+        g_create_error = "dtype must be HRN_F32 or HRN_BF16";
+        return 2;
+    }
+    if (max_batch <= 0) {
+        g_create_error = "max_batch must be positive";
+        return 2;
+    }
+    std::unique_ptr<hrn_ctx> h(new hrn_ctx());
+    h->c = c, h->joints = nof_joints, h->H = height, h->W = width, h->dtype = dtype, h->max_batch = max_batch;
+    h->device = device_id, h->plan_only = device_id < 0;
+    h->esize = dtype == HRN_BF16 ? 2 : 4;
+    if (!h->plan_only) {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || device_id >= ndev) {
+            g_create_error = "no such HIP device " + std::to_string(device_id) + " (" +
+                             (e != hipSuccess ? hipGetErrorString(e) : "device count " + std::to_string(ndev)) + ")";
+            return 3;
+        }
+    }
+    h->build_plan();
+    if (!h->allocate()) {
+        g_create_error = h->err.empty() ? "allocation failed" : h->err;
+        h->free_all();
+        return 4;
+    }
+    *out = h.release();
+    return 0;
+}
+
+void hrn_destroy(hrn_handle h) {
+    if (!h) return;
+    h->free_all();
+    delete h;
+}
+
+const char *hrn_last_error(hrn_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int hrn_load_weights(hrn_handle h, const hrn_tensor_desc *descs, int n) {
+    if (!h || !descs) return 1;
+    return h->load_weights(descs, n) ? 0 : 5;
+}
+
+int64_t hrn_weight_blob_bytes(hrn_handle h) { return h ? h->blob_bytes : 0; }
+void *hrn_weight_blob_ptr(hrn_handle h) { return h ? h->blob : nullptr; }
+int hrn_adopt_weights(hrn_handle h) {
+    if (!h) return 1;
+    h->weights_loaded = true;
+    return 0;
+}
+
+int hrn_weight_blob_read(hrn_handle h, int64_t offset, void *dst, int64_t nbytes) {
+    if (!h || !dst || offset < 0 || nbytes < 0 || offset + nbytes > h->blob_bytes) return 1;
+    if (h->plan_only) {
+        memcpy(dst, h->blob + offset, (size_t)nbytes);
+        return 0;
+    }
+    if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return 6;
+    return h->hip_ok(hipMemcpy(dst, h->blob + offset, (size_t)nbytes, hipMemcpyDeviceToHost), "hipMemcpy") ? 0 : 6;
+}
+
+int hrn_forward(hrn_handle h, const void *images_dev, int n, const void *boxes_dev, int box_dtype, float *pts_dev,
+                float *heatmaps_dev, void *stream) {
+    if (!h) return 1;
+    if (!h->check_forward_args(images_dev, n, boxes_dev, pts_dev, heatmaps_dev)) return 7;
+    if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return 6;
+    const int hm = (h->H / 4) * (h->W / 4);
+    for (int off = 0; off < n; off += h->max_batch) {
+        const int nb = n - off < h->max_batch ? n - off : h->max_batch;
+        const float *img = (const float *)images_dev + (size_t)off * 3 * h->H * h->W;
+        const void *bx = boxes_dev ? (const char *)boxes_dev + (size_t)off * 16 : nullptr;
+        float *p = pts_dev ? pts_dev + (size_t)off * h->joints * 3 : nullptr;
+        float *hp = heatmaps_dev ? heatmaps_dev + (size_t)off * h->joints * hm : nullptr;
+        if (!h->run_pass(img, nb, bx, box_dtype, p, hp, (hipStream_t)stream, nullptr)) return 8;
+    }
+    return 0;
+}
+
+int hrn_conv_count(hrn_handle h) { return h ? (int)h->convs.size() : 0; }
+
+int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out) {
+    if (!h || !out || index < 0 || index >= (int)h->convs.size()) return 1;
+    const ConvOp &cv = h->convs[index];
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", cv.conv.c_str());
+    out->cin = cv.cin, out->cout = cv.cout, out->ksize = cv.k, out->stride = cv.stride, out->relu = cv.relu;
+    out->has_residual = cv.res_t >= 0;
+    out->in_h = h->tensors[cv.in_t].h, out->in_w = h->tensors[cv.in_t].w;
+    out->out_h = h->tensors[cv.out_t].h, out->out_w = h->tensors[cv.out_t].w;
+    out->kpad = cv.kpad, out->nr = cv.nr;
+    out->w_offset = cv.w_off, out->w_bytes = cv.w_bytes, out->b_offset = cv.b_off;
+    out->flops = cv.flops;
+    return 0;
+}
+
+double hrn_flops_per_crop(hrn_handle h) {
+    if (!h) return 0;
+    double f = 2.0 * 64 * 27 * (h->H / 2) * (double)(h->W / 2);              // conv1
+    for (auto &cv : h->convs) f += cv.flops;
+    f += 2.0 * h->joints * h->c * (h->H / 4) * (double)(h->W / 4);           // final_layer
+    return f;
+}
+
+int64_t hrn_workspace_bytes(hrn_handle h) { return h ? h->workspace_bytes : 0; }
+int hrn_launches_per_pass(hrn_handle h) { return h ? (int)h->ops.size() : 0; }
+
+int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms, int conv_ms_len, float *other_ms,
+                     void *stream) {
+    if (!h) return 1;
+    if (n > h->max_batch) n = h->max_batch;
+    // profiling computes heat-map partials only (no pts): boxes are not needed
+    if (!h->check_forward_args(images_dev, n, nullptr, nullptr, (float *)1)) return 7;
+    if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return 6;
+    hrn_ctx::Timing tm;
+    tm.ev.resize(h->ops.size() + 1);
+    for (auto &e : tm.ev)
+        if (!h->hip_ok(hipEventCreate(&e), "hipEventCreate")) return 6;
+    bool ok = h->run_pass((const float *)images_dev, n, nullptr, 0, nullptr, nullptr, (hipStream_t)stream, &tm);
+    ok = ok && h->hip_ok(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+    if (ok) {
+        if (other_ms) other_ms[0] = other_ms[1] = other_ms[2] = other_ms[3] = 0.f;
+        for (int i = 0; i < conv_ms_len; ++i) conv_ms[i] = 0.f;
+        for (size_t oi = 0; oi < h->ops.size(); ++oi) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, tm.ev[oi], tm.ev[oi + 1]);
+            const Op &op = h->ops[oi];
+            if (op.kind == OP_CONV) {
+                if (conv_ms && op.idx < conv_ms_len) conv_ms[op.idx] = ms;
+            } else if (other_ms) {
+                const int slot = op.kind == OP_STEM ? 0 : op.kind == OP_FUSE ? 1 : op.kind == OP_HEAD ? 2 : 3;
+                other_ms[slot] += ms;
+            }
+        }
+    }
+    for (auto &e : tm.ev) (void)hipEventDestroy(e);
+    return ok ? 0 : 8;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// Device-side interface of the HRNet hot path: argument blocks + launchers.
+// Everything here is gfx950 (CDNA4) only; see DESIGN.md for layouts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hrn {
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+// Activation tensors use the "flat padded NHWC" layout:
+//   row(n, r, c) = n*Hp*Wp + r*Wp + c,  Wp = W+1, Hp = H+1, C channels per row,
+//   the extra column / row of every image hold zeros, as do the guard rows before
+//   image 0 and after the last image.  A 3x3/pad-1 tap (dh,dw) is then the constant
+//   row shift dh*Wp+dw -- no boundary tests in the inner loop.
+struct ConvArgs {
+    const void *in;     // row 0 of the input tensor
+    void *out;          // row 0 of the output tensor
+    const void *w;      // packed weights (fragment-major, see pack_conv_weights)
+    const float *bias;  // folded BN bias, fp32[cout]
+    const void *res;    // residual tensor (same geometry as out) or nullptr
+    int cin, cout;
+    int in_wp, in_hpwp;                     // input row pitch / image pitch (rows)
+    int out_h, out_w, out_wp, out_hpwp;     // output geometry
+    int m;                                  // rows to produce = n * out_hpwp
+    int ksize, stride, relu;
+    int kchunks;                            // padded K / (32 bf16 | 16 f32)
+};
+
+struct StemArgs {          // conv1 3->64 3x3 s2 + BN + ReLU, NCHW fp32 in, flat padded out
+    const float *images;   // (n,3,H,W)
+    void *out;
+    const float *w;        // [27][64] fp32, folded
+    const float *bias;     // [64]
+    int n, H, W;           // input size
+    int out_h, out_w, out_wp, out_hpwp;
+};
+
+struct FuseTerm {
+    const void *ptr;
+    int shift;      // nearest-upsample factor 2^shift (0 = same resolution)
+    int wp, hpwp;   // geometry of the term tensor
+};
+struct FuseArgs {          // out = relu(sum_j term_j) in order j = 0..nterms-1
+    FuseTerm t[4];
+    int nterms;
+    void *out;
+    int c, h, w, wp, hpwp;
+    int m;                 // n * hpwp
+};
+
+struct HeadArgs {          // final 1x1 conv (+bias) and per-(crop, joint) partial arg-max
+    const void *in;        // fused branch 0, flat padded, c channels
+    const float *wgt;      // [joints][c] fp32
+    const float *bias;     // [joints]
+    float *heatmaps;       // (n,joints,h,w) fp32 NCHW or nullptr
+    float *part_val;       // [n][joints][slabs]
+    int *part_idx;
+    int n, c, joints, h, w, wp, hpwp, slabs, slab_px;
+};
+
+struct DecodeArgs {        // SimpleHRNet.py:297-308
+    const float *part_val;
+    const int *part_idx;
+    const void *boxes;     // (n,4) int32 or fp32
+    int box_is_float;
+    float *pts;            // (n,joints,3)
+    int n, joints, h, w, slabs;
+};
+
+hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s);
+hipError_t launch_stem(int dtype, const StemArgs &a, hipStream_t s);
+hipError_t launch_fuse(int dtype, const FuseArgs &a, hipStream_t s);
+hipError_t launch_head(int dtype, const HeadArgs &a, hipStream_t s);
+hipError_t launch_decode(const DecodeArgs &a, hipStream_t s);
+
+// rows per block of the conv kernels: buffers keep this many guard rows after the last image
+constexpr int kConvBlockRows = 256;
+
+}  // namespace hrn

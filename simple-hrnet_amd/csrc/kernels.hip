@@ -1,0 +1,450 @@
+// HIP kernels of the HRNet hot path for gfx950 (MI355X, CDNA4).  Hand-written; wave = 64.
+//
+//   conv_direct_kernel  generic implicit-GEMM convolution (1x1 / 3x3, stride 1 / 2) on MFMA with the
+//                       fused epilogue  out = [relu]( acc + bias [+ residual] ), zero at pad pixels.
+//                       bf16: v_mfma_f32_16x16x32_bf16 (fp32 accumulate); fp32: v_mfma_f32_16x16x4_f32
+//                       (exact fp32 fma chain).  Operands are swapped (D = W * X^T) so that one lane owns
+//                       4*NR *contiguous* output channels of one pixel -> wide NHWC stores.
+//   stem_kernel         conv1 (3->64, 3x3 s2) + BN + ReLU straight from the caller's NCHW fp32 crops.
+//   fuse_kernel         cross-resolution sum (nearest upsample folded into the read index) + ReLU.
+//   head_kernel         final 1x1 conv + bias, optional heat-map write-out, per-slab arg-max.
+//   decode_kernel       arg-max merge (first maximum wins) + box scaling in fp64, SimpleHRNet.py:297-308.
+#include "kernels.h"
+
+namespace hrn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {  // round to nearest even
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <int DT>
+struct Tr;
+template <>
+struct Tr<DT_BF16> {
+    using elem = unsigned short;
+    using vec = s16x8;   // 8 bf16 = 16 B = one MFMA operand
+    using out4 = s16x4;  // 4 output channels
+    static constexpr int KC = 32, VEC = 8;
+    static __device__ __forceinline__ float ld(elem e) { return bf16_to_f32(e); }
+    static __device__ __forceinline__ elem st(float f) { return f32_to_bf16(f); }
+};
+template <>
+struct Tr<DT_F32> {
+    using elem = float;
+    using vec = f32x4;  // 4 fp32 = 16 B = four 16x16x4 MFMA steps
+    using out4 = f32x4;
+    static constexpr int KC = 16, VEC = 4;
+    static __device__ __forceinline__ float ld(elem e) { return e; }
+    static __device__ __forceinline__ elem st(float f) { return f; }
+};
+
+template <int DT>
+__device__ __forceinline__ f32x4 mma(typename Tr<DT>::vec w, typename Tr<DT>::vec x, f32x4 acc);
+template <>
+__device__ __forceinline__ f32x4 mma<DT_BF16>(s16x8 w, s16x8 x, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0,
+                                                   0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mma<DT_F32>(f32x4 w, f32x4 x, f32x4 acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], x[t], acc, 0, 0, 0);
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Generic convolution.  GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[k][pixel], k = tap*cin + ci.
+//   block = 4 waves, wave = 16*MR pixels x 16*NR couts, grid = (ceil(m / (64*MR)), cout / (16*NR)).
+//   lane (li = lane&15, g = lane>>4):  X operand = pixel li, k-group g (VEC consecutive ci of one tap);
+//   W operand = packed row li, k-group g (pre-packed so the load is lane-linear: lane*16 B).
+//   result: lane holds pixel li, channels ch0 + [0, 4*NR), ch0 = ng*16*NR + g*4*NR  (see pack_conv_weights).
+template <int DT, int NR, int MR>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
+    using T = Tr<DT>;
+    using vec = typename T::vec;
+    using elem = typename T::elem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int m0 = (blockIdx.x * 4 + wave) * (16 * MR);
+    const int ng = blockIdx.y;
+    const elem *__restrict__ in = (const elem *)p.in;
+
+    long inrow[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int q = m0 + i * 16 + li;
+        int r;
+        if (q >= p.m) {
+            r = 0;  // masked at the store; any mapped row will do
+        } else if (p.stride == 1) {
+            r = q;
+        } else {
+            const int n = q / p.out_hpwp, rem = q - n * p.out_hpwp;
+            const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
+            r = n * p.in_hpwp + 2 * ho * p.in_wp + 2 * wo;
+        }
+        inrow[i] = (long)r * p.cin;
+    }
+
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int ci = g * T::VEC, tap = 0;
+    while (ci >= p.cin) {
+        ci -= p.cin;
+        ++tap;
+    }
+    const int ntaps = p.ksize * p.ksize;
+    const char *__restrict__ wlane = (const char *)p.w + ((size_t)ng * NR * p.kchunks * 64 + lane) * 16;
+
+    for (int kc = 0; kc < p.kchunks; ++kc) {
+        vec b[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) b[j] = *(const vec *)(wlane + ((size_t)j * p.kchunks + kc) * 1024);
+        vec a[MR];
+        if (tap < ntaps) {
+            int tapoff = 0;
+            if (p.ksize == 3) {
+                const int dh = (tap * 11) >> 5, dw = tap - dh * 3;
+                tapoff = (dh - 1) * p.in_wp + (dw - 1);
+            }
+            const long aoff = (long)tapoff * p.cin + ci;
+#pragma unroll
+            for (int i = 0; i < MR; ++i) a[i] = *(const vec *)(in + inrow[i] + aoff);
+        } else {  // K padding: weights are zero there, feed zeros
+#pragma unroll
+            for (int i = 0; i < MR; ++i) a[i] = vec{};
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) acc[i][j] = mma<DT>(b[j], a[i], acc[i][j]);
+        ci += T::KC;
+        while (ci >= p.cin) {
+            ci -= p.cin;
+            ++tap;
+        }
+    }
+
+    // ---- epilogue: bias (+ residual) (+ ReLU), zero on pad pixels, 4*NR contiguous channels per lane
+    const int ch0 = ng * 16 * NR + g * 4 * NR;
+    float bias[4 * NR];
+#pragma unroll
+    for (int c = 0; c < 4 * NR; ++c) bias[c] = p.bias[ch0 + c];
+    elem *__restrict__ out = (elem *)p.out;
+    const elem *__restrict__ res = (const elem *)p.res;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int q = m0 + i * 16 + li;
+        if (q >= p.m) continue;
+        const int rem = q % p.out_hpwp;
+        const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
+        const bool ok = (ho < p.out_h) && (wo < p.out_w);
+        const size_t o = (size_t)q * p.cout + ch0;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            typename T::out4 r4 = {};
+            if (res) r4 = *(const typename T::out4 *)(res + o + j * 4);
+            typename T::out4 o4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r] + bias[j * 4 + r];
+                if (res) v += T::ld((elem)r4[r]);
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (!ok) v = 0.f;
+                o4[r] = T::st(v);
+            }
+            *(typename T::out4 *)(out + o + j * 4) = o4;
+        }
+    }
+}
+
+template <int DT, int NR>
+static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
+    constexpr int MR = 4;
+    dim3 grid((a.m + 64 * MR - 1) / (64 * MR), a.cout / (16 * NR));
+    hipLaunchKernelGGL((conv_direct_kernel<DT, NR, MR>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s) {
+    if (a.m <= 0) return hipSuccess;
+    if (dtype == DT_BF16) {
+        if (nr == 4) return launch_conv_t<DT_BF16, 4>(a, s);
+        if (nr == 3) return launch_conv_t<DT_BF16, 3>(a, s);
+        if (nr == 2) return launch_conv_t<DT_BF16, 2>(a, s);
+    } else {
+        if (nr == 4) return launch_conv_t<DT_F32, 4>(a, s);
+        if (nr == 3) return launch_conv_t<DT_F32, 3>(a, s);
+        if (nr == 2) return launch_conv_t<DT_F32, 2>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stem conv1: 3->64, 3x3, stride 2, pad 1 (+folded BN, ReLU).  Input is the caller's NCHW fp32 batch,
+// arithmetic is fp32 in both modes.  blockIdx.y = group of 16 output channels (weights are block-uniform
+// -> scalar loads), threadIdx -> output row q of the flat padded layout.
+template <int DT>
+__global__ __launch_bounds__(256) void stem_kernel(const StemArgs p) {
+    using T = Tr<DT>;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int m = p.n * p.out_hpwp;
+    if (q >= m) return;
+    const int cg = blockIdx.y;
+    const int n = q / p.out_hpwp, rem = q - n * p.out_hpwp;
+    const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
+    float acc[16];
+    const bool ok = ho < p.out_h && wo < p.out_w;
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = p.bias[cg * 16 + c];
+        const float *img = p.images + (size_t)n * 3 * p.H * p.W;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int iy = 2 * ho + kh - 1;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ix = 2 * wo + kw - 1;
+                    float x = 0.f;
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) x = img[((size_t)ci * p.H + iy) * p.W + ix];
+                    const float *wk = p.w + (ci * 9 + kh * 3 + kw) * 64 + cg * 16;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) acc[c] = fmaf(x, wk[c], acc[c]);
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = fmaxf(acc[c], 0.f);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    }
+    typename T::elem *o = (typename T::elem *)p.out + (size_t)q * 64 + cg * 16;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        typename T::out4 o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = T::st(acc[v * 4 + r]);
+        *(typename T::out4 *)(o + v * 4) = o4;
+    }
+}
+
+hipError_t launch_stem(int dtype, const StemArgs &a, hipStream_t s) {
+    const int m = a.n * a.out_hpwp;
+    if (m <= 0) return hipSuccess;
+    dim3 grid((m + 255) / 256, 4);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(stem_kernel<DT_BF16>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(stem_kernel<DT_F32>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Cross-resolution fuse (hrnet.py:60-69): out = relu(t0 + t1 + ...), left to right, fp32.
+// A term with shift s is a lower-resolution tensor read at (r>>s, c>>s) (nn.Upsample nearest, integer
+// scale).  Pad pixels map to pad pixels, so zeros propagate without a mask.
+template <int DT>
+__global__ __launch_bounds__(256) void fuse_kernel(const FuseArgs p) {
+    using T = Tr<DT>;
+    using vec = typename T::vec;
+    const int cvn = p.c / T::VEC;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)p.m * cvn;
+    if (idx >= total) return;
+    const int q = (int)(idx / cvn), cv = (int)(idx - (long)q * cvn);
+    const int n = q / p.hpwp, rem = q - n * p.hpwp;
+    const int r = rem / p.wp, c = rem - r * p.wp;
+    float sum[T::VEC];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t >= p.nterms) break;
+        const FuseTerm ft = p.t[t];
+        const long row = ft.shift == 0 ? (long)q : (long)n * ft.hpwp + (long)(r >> ft.shift) * ft.wp + (c >> ft.shift);
+        const vec v = *(const vec *)((const typename T::elem *)ft.ptr + row * p.c + cv * T::VEC);
+#pragma unroll
+        for (int e = 0; e < T::VEC; ++e) {
+            const float f = T::ld((typename T::elem)v[e]);
+            sum[e] = (t == 0) ? f : sum[e] + f;
+        }
+    }
+    vec o;
+#pragma unroll
+    for (int e = 0; e < T::VEC; ++e) o[e] = T::st(fmaxf(sum[e], 0.f));
+    *(vec *)((typename T::elem *)p.out + (long)q * p.c + cv * T::VEC) = o;
+}
+
+hipError_t launch_fuse(int dtype, const FuseArgs &a, hipStream_t s) {
+    const long total = (long)a.m * (a.c / (dtype == DT_BF16 ? 8 : 4));
+    if (total <= 0) return hipSuccess;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(fuse_kernel<DT_BF16>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(fuse_kernel<DT_F32>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Head: final_layer 1x1 conv c->joints WITH bias (hrnet.py:155,187), fp32 weights/accumulate.
+// grid = (slabs, n); each block scans slab_px pixels of one crop, optionally writes the NCHW fp32
+// heat-maps, and leaves one (max, first index) candidate per joint.
+constexpr int kMaxJoints = 32;
+
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+template <int DT>
+__global__ __launch_bounds__(256) void head_kernel(const HeadArgs p) {
+    using T = Tr<DT>;
+    using vec = typename T::vec;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *wsh = smem;                       // [joints][c]
+    float *red_v = smem + p.joints * p.c;    // [4][joints]
+    int *red_i = (int *)(red_v + 4 * kMaxJoints);
+    for (int i = threadIdx.x; i < p.joints * p.c; i += 256) wsh[i] = p.wgt[i];
+    __syncthreads();
+    const int slab = blockIdx.x, n = blockIdx.y;
+    const int hw = p.h * p.w;
+    const int px_end = min(hw, (slab + 1) * p.slab_px);
+    float bv[kMaxJoints];
+    int bi[kMaxJoints];
+#pragma unroll
+    for (int j = 0; j < kMaxJoints; ++j) {
+        bv[j] = -INFINITY;
+        bi[j] = 0x7fffffff;
+    }
+    for (int px = slab * p.slab_px + threadIdx.x; px < px_end; px += 256) {
+        const int r = px / p.w, c = px - r * p.w;
+        const typename T::elem *row = (const typename T::elem *)p.in + ((size_t)n * p.hpwp + r * p.wp + c) * p.c;
+        float acc[kMaxJoints];
+#pragma unroll
+        for (int j = 0; j < kMaxJoints; ++j) acc[j] = 0.f;
+        for (int c0 = 0; c0 < p.c; c0 += T::VEC) {
+            const vec v = *(const vec *)(row + c0);
+#pragma unroll
+            for (int e = 0; e < T::VEC; ++e) {
+                const float x = T::ld((typename T::elem)v[e]);
+#pragma unroll
+                for (int j = 0; j < kMaxJoints; ++j)
+                    if (j < p.joints) acc[j] = fmaf(x, wsh[j * p.c + c0 + e], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxJoints; ++j) {
+            if (j < p.joints) {
+                const float v = acc[j] + p.bias[j];
+                if (p.heatmaps) p.heatmaps[((size_t)n * p.joints + j) * hw + px] = v;
+                if (v > bv[j]) {  // px increases monotonically per thread: strict > keeps the first maximum
+                    bv[j] = v;
+                    bi[j] = px;
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < kMaxJoints; ++j) {
+        if (j < p.joints) {
+            float v = bv[j];
+            int i = bi[j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(v, off);
+                const int oi = __shfl_xor(i, off);
+                if (better(ov, oi, v, i)) {
+                    v = ov;
+                    i = oi;
+                }
+            }
+            if (lane == 0) {
+                red_v[wave * kMaxJoints + j] = v;
+                red_i[wave * kMaxJoints + j] = i;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < p.joints) {
+        const int j = threadIdx.x;
+        float v = red_v[j];
+        int i = red_i[j];
+        for (int w = 1; w < 4; ++w)
+            if (better(red_v[w * kMaxJoints + j], red_i[w * kMaxJoints + j], v, i)) {
+                v = red_v[w * kMaxJoints + j];
+                i = red_i[w * kMaxJoints + j];
+            }
+        p.part_val[((size_t)n * p.joints + j) * p.slabs + slab] = v;
+        p.part_idx[((size_t)n * p.joints + j) * p.slabs + slab] = i;
+    }
+}
+
+hipError_t launch_head(int dtype, const HeadArgs &a, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    if (a.joints > kMaxJoints) return hipErrorInvalidValue;
+    dim3 grid(a.slabs, a.n);
+    const size_t shm = sizeof(float) * ((size_t)a.joints * a.c + 4 * kMaxJoints) + sizeof(int) * 4 * kMaxJoints;
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(head_kernel<DT_BF16>, grid, dim3(256), shm, s, a);
+    else
+        hipLaunchKernelGGL(head_kernel<DT_F32>, grid, dim3(256), shm, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Decode (SimpleHRNet.py:297-308): merge the slab candidates (lowest flat index among equal maxima =
+// np.argmax), then  y = py * 1. / h * (y2 - y1) + y1,  x = px * 1. / w * (x2 - x1) + x1  evaluated in
+// float64 exactly as numpy does (box difference first, in the boxes' own dtype), stored as fp32.
+__global__ void decode_kernel(const DecodeArgs p) {
+#pragma clang fp contract(off)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.n * p.joints) return;
+    const int n = t / p.joints;
+    float v = -INFINITY;
+    int i = 0x7fffffff;
+    for (int s = 0; s < p.slabs; ++s) {
+        const float ov = p.part_val[(size_t)t * p.slabs + s];
+        const int oi = p.part_idx[(size_t)t * p.slabs + s];
+        if (better(ov, oi, v, i)) {
+            v = ov;
+            i = oi;
+        }
+    }
+    const int py = i / p.w, px = i - py * p.w;
+    double x1, y1, dx, dy;
+    if (p.box_is_float) {
+        const float *b = (const float *)p.boxes + 4 * (size_t)n;
+        x1 = b[0], y1 = b[1];
+        dx = (double)(b[2] - b[0]);  // fp32 subtraction first, like numpy float32 scalars
+        dy = (double)(b[3] - b[1]);
+    } else {
+        const int *b = (const int *)p.boxes + 4 * (size_t)n;
+        x1 = b[0], y1 = b[1];
+        dx = (double)(b[2] - b[0]);
+        dy = (double)(b[3] - b[1]);
+    }
+    float *o = p.pts + (size_t)t * 3;
+    o[0] = (float)((double)py * 1. / (double)p.h * dy + y1);
+    o[1] = (float)((double)px * 1. / (double)p.w * dx + x1);
+    o[2] = v;
+}
+
+hipError_t launch_decode(const DecodeArgs &a, hipStream_t s) {
+    const int total = a.n * a.joints;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(decode_kernel, dim3((total + 127) / 128), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace hrn

@@ -1,0 +1,229 @@
+"""Host-side mirror of the reference's model seam, backed by the C ABI (include/hrnet_mi355.h).
+
+``NativeHRNet`` is assignable to ``SimpleHRNet.model`` -- the reference invokes it as
+``self.model(images)`` under ``torch.no_grad()`` and consumes ``.detach().cpu().numpy()``
+(SimpleHRNet.py:284-296, 419-431), exactly as it does for its own TensorRT swap
+(SimpleHRNet.py:143-147) -- and additionally offers the fused ``predict_crops`` (model call +
+arg-max decode on the GPU, replacing SimpleHRNet.py:281-308 / 416-443).
+
+PyTorch is used only as the container for device memory and for the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+
+DTYPES = {"fp32": 0, "f32": 0, "float32": 0, torch.float32: 0, "bf16": 1, "bfloat16": 1, torch.bfloat16: 1}
+
+
+def _device_index(device) -> int:
+    if isinstance(device, int):
+        return device
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise ValueError("Wrong device name.")  # same message as SimpleHRNet.py:139
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+class NativeHRNet:
+    """HRNet-W{c} pose network compiled to hand-written gfx950 kernels.
+
+    Parameters mirror ``HRNet(c, nof_joints)`` (models_/hrnet.py:75) plus what a static engine
+    needs up front: input ``resolution`` (h, w), arithmetic ``dtype`` ('bf16' MFMA with fp32
+    accumulate, or 'fp32' exact-fp32 MFMA), and ``max_batch`` = crops per internal pass.
+    ``device=-1`` builds a plan-only handle (graph + weight packing on the host, no GPU): it cannot
+    run -- there is no CPU compute path.
+    """
+
+    def __init__(self, c: int = 48, nof_joints: int = 17, resolution: Tuple[int, int] = (384, 288),
+                 dtype: Union[str, torch.dtype] = "bf16", max_batch: int = 32, device=0):
+        if dtype not in DTYPES:
+            raise ValueError("dtype must be 'bf16' or 'fp32'")
+        self.c, self.nof_joints = int(c), int(nof_joints)
+        self.resolution = (int(resolution[0]), int(resolution[1]))
+        self.dtype = "bf16" if DTYPES[dtype] == 1 else "fp32"
+        self.max_batch = int(max_batch)
+        self.device_index = -1 if (isinstance(device, int) and device < 0) else _device_index(device)
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.hrn_create(ctypes.byref(self._h), self.c, self.nof_joints, self.resolution[0],
+                                  self.resolution[1], DTYPES[dtype], self.max_batch, self.device_index)
+        if rc != 0:
+            msg = self._lib.hrn_last_error(None).decode()
+            self._h = ctypes.c_void_p()
+            raise (ValueError if rc == 2 else RuntimeError)("hrn_create failed: " + msg)
+        self._keep = None
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.hrn_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self._lib.hrn_last_error(self._h).decode()))
+
+    # -- nn.Module look-alikes the reference calls on self.model (SimpleHRNet.py:141-142) --------
+    def eval(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        return self
+
+    @property
+    def torch_device(self) -> torch.device:
+        return torch.device("cuda", self.device_index)
+
+    # -- weights --------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Dict) -> "NativeHRNet":
+        """Accepts what ``torch.load(checkpoint)`` yields: a raw ``state_dict`` or ``{'model': ...}``
+        (SimpleHRNet.py:117-121); values may be torch tensors or numpy arrays."""
+        if "model" in state_dict and not hasattr(state_dict["model"], "shape"):
+            state_dict = state_dict["model"]
+        keep, descs = [], []
+        for k, v in state_dict.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            a = np.asarray(v)
+            if a.dtype == np.int64:
+                code = 1
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float32)
+                code = 0
+            if a.ndim > 4:
+                raise ValueError("state_dict entry %s has %d dims" % (k, a.ndim))
+            keep.append(a)
+            dims = (ctypes.c_int64 * 4)(*(list(a.shape) + [0] * (4 - a.ndim)))
+            descs.append(_lib.TensorDesc(k.encode(), a.ctypes.data_as(ctypes.c_void_p), a.ndim, dims, code))
+        arr = (_lib.TensorDesc * len(descs))(*descs)
+        rc = self._lib.hrn_load_weights(self._h, arr, len(descs))
+        if rc != 0:
+            raise KeyError("hrn_load_weights: " + self._lib.hrn_last_error(self._h).decode())
+        return self
+
+    def load_checkpoint(self, path: str) -> "NativeHRNet":
+        return self.load_state_dict(torch.load(path, map_location="cpu"))
+
+    # -- multi-GPU weight distribution (RCCL broadcast of the packed blob) -------------------------
+    def weight_blob_bytes(self) -> int:
+        return int(self._lib.hrn_weight_blob_bytes(self._h))
+
+    def weight_blob_tensor(self) -> torch.Tensor:
+        """uint8 CUDA tensor aliasing the packed-weight blob (zero-copy, for torch.distributed)."""
+
+        class _Raw:
+            pass
+
+        raw = _Raw()
+        raw.__cuda_array_interface__ = {"shape": (self.weight_blob_bytes(),), "typestr": "|u1",
+                                        "data": (int(self._lib.hrn_weight_blob_ptr(self._h)), False), "version": 2}
+        raw._owner = self
+        with torch.cuda.device(self.device_index):
+            return torch.as_tensor(raw, device=self.torch_device)
+
+    def adopt_weights(self):
+        self._check(self._lib.hrn_adopt_weights(self._h), "hrn_adopt_weights")
+
+    def read_blob(self, offset: int, nbytes: int) -> np.ndarray:
+        out = np.empty(nbytes, dtype=np.uint8)
+        self._check(self._lib.hrn_weight_blob_read(self._h, offset, out.ctypes.data_as(ctypes.c_void_p), nbytes),
+                    "hrn_weight_blob_read")
+        return out
+
+    # -- the hot path ---------------------------------------------------------------------------
+    def _images_ptr(self, images: torch.Tensor) -> torch.Tensor:
+        if not isinstance(images, torch.Tensor):
+            raise TypeError("images must be a torch.Tensor (n,3,H,W)")
+        h, w = self.resolution
+        if images.dim() != 4 or tuple(images.shape[1:]) != (3, h, w):
+            raise ValueError("images must have shape (n,3,%d,%d), got %s" % (h, w, tuple(images.shape)))
+        if images.device.type != "cuda":
+            images = images.to(self.torch_device, non_blocking=True)
+        elif images.device.index != self.device_index:
+            raise ValueError("images live on %s, engine on cuda:%d" % (images.device, self.device_index))
+        return images.to(torch.float32).contiguous()
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device_index).cuda_stream
+
+    def __call__(self, images: torch.Tensor) -> torch.Tensor:
+        """``self.model(images)``: (n,3,H,W) fp32 -> heat-maps (n,J,H/4,W/4) fp32 on the same GPU."""
+        x = self._images_ptr(images)
+        n = x.shape[0]
+        h, w = self.resolution
+        out = torch.empty((n, self.nof_joints, h // 4, w // 4), dtype=torch.float32, device=x.device)
+        if n:
+            with torch.cuda.device(self.device_index):
+                self._check(self._lib.hrn_forward(self._h, x.data_ptr(), n, None, 0, None, out.data_ptr(),
+                                                  self._stream()), "hrn_forward")
+        return out
+
+    forward = __call__
+
+    def predict_crops(self, images: torch.Tensor, boxes, return_heatmaps: bool = False):
+        """Model call + decode (SimpleHRNet.py:281-308): returns ``pts`` (n,J,3) fp32 CUDA tensor of
+        ``(y, x, confidence)``; with ``return_heatmaps`` also the (n,J,H/4,W/4) heat-maps.
+        ``boxes``: (n,4) ``[x1,y1,x2,y2]`` int32 (multi-person path) or float32 (single-person)."""
+        x = self._images_ptr(images)
+        n = x.shape[0]
+        b = boxes if isinstance(boxes, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(boxes))
+        if tuple(b.shape) != (n, 4):
+            raise ValueError("boxes must have shape (%d,4), got %s" % (n, tuple(b.shape)))
+        if b.dtype in (torch.int32, torch.int64, torch.int16, torch.uint8):
+            b, box_dtype = b.to(torch.int32), 0
+        else:
+            b, box_dtype = b.to(torch.float32), 1
+        b = b.to(x.device).contiguous()
+        h, w = self.resolution
+        pts = torch.empty((n, self.nof_joints, 3), dtype=torch.float32, device=x.device)
+        hm = torch.empty((n, self.nof_joints, h // 4, w // 4), dtype=torch.float32,
+                         device=x.device) if return_heatmaps else None
+        if n:
+            with torch.cuda.device(self.device_index):
+                self._check(self._lib.hrn_forward(self._h, x.data_ptr(), n, b.data_ptr(), box_dtype, pts.data_ptr(),
+                                                  hm.data_ptr() if hm is not None else None, self._stream()),
+                            "hrn_forward")
+        return (hm, pts) if return_heatmaps else pts
+
+    # -- introspection --------------------------------------------------------------------------
+    def conv_infos(self) -> List[_lib.ConvInfo]:
+        out = []
+        for i in range(self._lib.hrn_conv_count(self._h)):
+            ci = _lib.ConvInfo()
+            self._check(self._lib.hrn_get_conv_info(self._h, i, ctypes.byref(ci)), "hrn_get_conv_info")
+            out.append(ci)
+        return out
+
+    def flops_per_crop(self) -> float:
+        return float(self._lib.hrn_flops_per_crop(self._h))
+
+    def workspace_bytes(self) -> int:
+        return int(self._lib.hrn_workspace_bytes(self._h))
+
+    def launches_per_pass(self) -> int:
+        return int(self._lib.hrn_launches_per_pass(self._h))
+
+    def profile_pass(self, images: torch.Tensor):
+        """HIP-event time of every kernel of ONE internal pass over ``images[:max_batch]``.
+        Returns (conv_ms[list], other_ms{stem,fuse,head,decode})."""
+        x = self._images_ptr(images)
+        n = min(x.shape[0], self.max_batch)
+        nconv = self._lib.hrn_conv_count(self._h)
+        conv_ms = (ctypes.c_float * nconv)()
+        other = (ctypes.c_float * 4)()
+        with torch.cuda.device(self.device_index):
+            self._check(self._lib.hrn_profile_pass(self._h, x.data_ptr(), n, conv_ms, nconv, other, self._stream()),
+                        "hrn_profile_pass")
+        return list(conv_ms), dict(zip(("stem", "fuse", "head", "decode"), list(other)))

@@ -1,0 +1,118 @@
+"""Host-side logic of the native library on a CPU-only box: the C ABI loads and exports every symbol
+the header declares, the graph compiler reproduces the reference's op census and FLOP count, BN folding
+and MFMA-fragment packing are correct.  No compute entry point is called (there is no CPU compute path)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg, state_dict_np
+
+pkg = load_pkg()
+_lib = load_pkg("_lib")
+
+
+def test_library_exports_every_header_symbol():
+    lib = _lib.load()
+    declared = _lib.header_symbols()
+    assert set(declared) == set(_lib.SYMBOLS), (declared, sorted(_lib.SYMBOLS))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.hrn_version()
+
+
+@pytest.mark.parametrize("c,res,gflop", [(32, (256, 192), 15.290), (48, (384, 288), 70.613)])
+def test_plan_census_matches_survey(c, res, gflop):
+    net = pkg.NativeHRNet(c, 17, res, "bf16", max_batch=4, device=-1)
+    infos = net.conv_infos()
+    # 293 Conv2d in the reference; conv1 (stem kernel) and final_layer (head kernel) are not
+    # generic-conv ops here
+    assert len(infos) == 291
+    assert abs(net.flops_per_crop() / 1e9 - gflop) < 0.002 * gflop
+    names = [i.name.decode() for i in infos]
+    spec = {k[:-len(".weight")] for k, s, kind in pkg.synth.hrnet_state_spec(c, 17) if kind == "conv"}
+    assert set(names) == spec - {"conv1", "final_layer"}
+    # hot convs: 208 BasicBlock 3x3 s1 convs, each 0.28665 GFLOP at W48 384x288
+    hot = [i for i in infos if ".branches." in i.name.decode()]
+    assert len(hot) == 208
+    if c == 48:
+        assert all(abs(i.flops / 1e9 - 0.28665) < 1e-4 for i in hot)
+    net.close()
+
+
+def test_bad_arguments_raise():
+    with pytest.raises(ValueError):
+        pkg.NativeHRNet(48, 17, (384, 280), "bf16", device=-1)      # not a multiple of 32
+    with pytest.raises(ValueError):
+        pkg.NativeHRNet(40, 17, (384, 288), "bf16", device=-1)      # c not a multiple of 16
+    with pytest.raises(ValueError):
+        pkg.NativeHRNet(48, 17, (384, 288), "int8", device=-1)
+    with pytest.raises(ValueError):
+        pkg.NativeHRNet(48, 17, (384, 288), "bf16", device="cpu")   # 'Wrong device name.' like SimpleHRNet.py:139
+    net = pkg.NativeHRNet(32, 17, (64, 64), "fp32", max_batch=2, device=-1)
+    sd = dict(state_dict_np(32))
+    del sd["stage3.2.branches.1.0.bn1.running_var"]
+    with pytest.raises(KeyError, match="stage3.2.branches.1.0.bn1.running_var"):
+        net.load_state_dict(sd)
+    # a plan-only handle must refuse to compute: there is NO CPU fallback
+    net.load_state_dict(state_dict_np(32))
+    rc = net._lib.hrn_forward(net._h, ctypes.c_void_p(16), 1, None, 0, None, ctypes.c_void_p(16), None)
+    assert rc != 0 and b"no CPU compute path" in net._lib.hrn_last_error(net._h)
+    net.close()
+
+
+def _unpack(net, info, dtype):
+    """inverse of the documented fragment-major layout"""
+    kc, vec = (32, 8) if dtype == "bf16" else (16, 4)
+    raw = net.read_blob(info.w_offset, info.w_bytes)
+    if dtype == "bf16":
+        u = raw.view(np.uint16).astype(np.uint32) << 16
+        vals = u.view(np.float32)
+    else:
+        vals = raw.view(np.float32)
+    kchunks = info.kpad // kc
+    vals = vals.reshape(info.cout // 16, kchunks, 64, vec)
+    out = np.zeros((info.cout, info.kpad), np.float32)
+    for f in range(info.cout // 16):
+        ng, j = divmod(f, info.nr)
+        for lane in range(64):
+            li, g = lane & 15, lane >> 4
+            co = ng * 16 * info.nr + (li >> 2) * 4 * info.nr + j * 4 + (li & 3)
+            for k in range(kchunks):
+                out[co, k * kc + g * vec:k * kc + (g + 1) * vec] = vals[f, k, lane]
+    return out
+
+
+def _bf16_round(a):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return t.to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fold_and_pack(dtype):
+    c = 48
+    sd = state_dict_np(c)
+    net = pkg.NativeHRNet(c, 17, (64, 64), dtype, max_batch=1, device=-1).load_state_dict(sd)
+    infos = {i.name.decode(): i for i in net.conv_infos()}
+    cases = [("conv2", "bn2"), ("layer1.0.conv1", "layer1.0.bn1"), ("transition1.0.0", "transition1.0.1"),
+             ("stage3.1.branches.2.3.conv2", "stage3.1.branches.2.3.bn2"),
+             ("stage4.0.fuse_layers.3.0.2.0", "stage4.0.fuse_layers.3.0.2.1"),
+             ("stage4.2.fuse_layers.0.3.0", "stage4.2.fuse_layers.0.3.1")]
+    for conv, bn in cases:
+        info = infos[conv]
+        w = sd[conv + ".weight"].astype(np.float64)
+        scale = sd[bn + ".weight"].astype(np.float64) / np.sqrt(sd[bn + ".running_var"].astype(np.float64) + 1e-5)
+        shift = sd[bn + ".bias"].astype(np.float64) - sd[bn + ".running_mean"].astype(np.float64) * scale
+        cout, cin, kh, kw = w.shape
+        assert (info.cout, info.cin, info.ksize) == (cout, cin, kh)
+        want = (w * scale[:, None, None, None]).transpose(0, 2, 3, 1).reshape(cout, kh * kw * cin)  # k = tap*cin+ci
+        want = want.astype(np.float32)
+        if dtype == "bf16":
+            want = _bf16_round(want)
+        got = _unpack(net, info, dtype)
+        np.testing.assert_array_equal(got[:, :want.shape[1]], want)
+        assert not got[:, want.shape[1]:].any()          # K padding is zero
+        bias = net.read_blob(info.b_offset, 4 * cout).view(np.float32)
+        np.testing.assert_allclose(bias, shift.astype(np.float32), rtol=0, atol=0)
+    net.close()
