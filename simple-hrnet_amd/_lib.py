@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libhrnet_mi355.so")
-SOURCES = ["kernels.hip", "hrnet_mi355.cpp"]
+SOURCES = ["kernels.hip", "conv3x3_lds.hip", "hrnet_mi355.cpp"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(INCLUDE, "hrnet_mi355.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
@@ -59,6 +59,7 @@ class ConvInfo(ctypes.Structure):
                 ("stride", ctypes.c_int32), ("relu", ctypes.c_int32), ("has_residual", ctypes.c_int32),
                 ("in_h", ctypes.c_int32), ("in_w", ctypes.c_int32), ("out_h", ctypes.c_int32),
                 ("out_w", ctypes.c_int32), ("kpad", ctypes.c_int32), ("nr", ctypes.c_int32),
+                ("algo", ctypes.c_int32), ("ks", ctypes.c_int32),
                 ("w_offset", ctypes.c_int64), ("w_bytes", ctypes.c_int64), ("b_offset", ctypes.c_int64),
                 ("flops", ctypes.c_double)]
 

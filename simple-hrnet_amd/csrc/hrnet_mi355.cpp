@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -42,6 +43,8 @@ struct ConvOp {
     int in_t, out_t, res_t;
     int cin, cout, k, stride, relu;
     int kpad, kchunks, nr;
+    int algo = 0;          // 0 = generic direct kernel, 1 = LDS-staged 3x3 s1 (conv3x3_lds.hip)
+    int ks = 0, slices = 0, ntiles = 0, nch = 0;
     int64_t w_off = 0, w_bytes = 0, b_off = 0;
     double flops = 0;
 };
@@ -87,6 +90,8 @@ struct hrn_ctx {
     char *blob = nullptr;  // device (or host when plan_only)
     bool weights_loaded = false;
 
+    bool disable_lds = getenv("HRN_DISABLE_LDS") != nullptr;
+    int conv3_variant = getenv("HRN_CONV3_VARIANT") ? atoi(getenv("HRN_CONV3_VARIANT")) : 0;
     int head_slabs = 1, head_slab_px = 1024;
     float *part_val = nullptr;
     int *part_idx = nullptr;
@@ -131,6 +136,11 @@ struct hrn_ctx {
         op.kpad = op.kchunks * kc;
         op.nr = (cout % 64 == 0) ? 4 : (cout % 48 == 0) ? 3 : 2;
         op.flops = 2.0 * cout * (double)K * oh * ow;
+        if (dtype == HRN_BF16 && k == 3 && stride == 1 && op.cin % 48 == 0 && cout % 48 == 0 && !disable_lds) {
+            op.algo = 1, op.ks = 48, op.nr = 3;
+            op.slices = op.cin / 48, op.ntiles = cout / 48, op.nch = (9 * 48 + 31) / 32;
+            op.kpad = op.nch * 32 * op.slices;
+        }
         convs.push_back(op);
         ops.push_back({OP_CONV, (int)convs.size() - 1});
         return op.out_t;
@@ -246,7 +256,8 @@ struct hrn_ctx {
         stem_b_off = off, off = align_up(off + 64 * 4, 256);
         for (auto &cv : convs) {
             cv.w_off = off;
-            cv.w_bytes = (int64_t)(cv.cout / 16) * cv.kchunks * 1024;
+            cv.w_bytes = cv.algo == 1 ? (int64_t)cv.ntiles * cv.slices * cv.nch * cv.nr * 1024
+                                      : (int64_t)(cv.cout / 16) * cv.kchunks * 1024;
             off = align_up(off + cv.w_bytes, 256);
             cv.b_off = off;
             off = align_up(off + cv.cout * 4, 256);
@@ -378,7 +389,10 @@ struct hrn_ctx {
                     for (int t = 0; t < kk; ++t)
                         wf[(size_t)co * K + t * cv.cin + ci] =
                             (float)((double)w[((size_t)co * cv.cin + ci) * kk + t] * scale[co]);
-            pack_conv(cv, wf.data(), K, host.data() + cv.w_off);
+            if (cv.algo == 1)
+                pack_conv_lds(cv, wf.data(), K, host.data() + cv.w_off);
+            else
+                pack_conv(cv, wf.data(), K, host.data() + cv.w_off);
             float *db = (float *)(host.data() + cv.b_off);
             for (int co = 0; co < cv.cout; ++co) db[co] = (float)shift[co];
         }
@@ -427,6 +441,32 @@ struct hrn_ctx {
         }
     }
 
+    // Slice-major image for conv3x3_lds_kernel: block (cout tile t, slice s) is the exact LDS image
+    // [chunk c][frag j][lane][8 bf16]; within a slice k = tap*KS + ci_local, zero beyond 9*KS.
+    void pack_conv_lds(const ConvOp &cv, const float *wf, int K, char *dst) const {
+        const int KS = cv.ks, NRB = cv.nr;
+        for (int t = 0; t < cv.ntiles; ++t)
+            for (int s = 0; s < cv.slices; ++s) {
+                uint16_t *blk = (uint16_t *)(dst + ((size_t)t * cv.slices + s) * cv.nch * NRB * 1024);
+                for (int c = 0; c < cv.nch; ++c)
+                    for (int j = 0; j < NRB; ++j)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int li = lane & 15, g = lane >> 4;
+                            const int co = t * 16 * NRB + (li >> 2) * 4 * NRB + j * 4 + (li & 3);
+                            uint16_t *d = blk + ((size_t)(c * NRB + j) * 64 + lane) * 8;
+                            for (int e = 0; e < 8; ++e) {
+                                const int kl = 32 * c + 8 * g + e;
+                                float v = 0.f;
+                                if (kl < 9 * KS) {
+                                    const int tap = kl / KS, cil = kl % KS;
+                                    v = wf[(size_t)co * K + tap * cv.cin + s * KS + cil];
+                                }
+                                d[e] = f32_to_bf16_host(v);
+                            }
+                        }
+            }
+    }
+
     // ---------------------------------------------------------------- execution
     struct Timing {
         std::vector<hipEvent_t> ev;  // ops.size()+1 events
@@ -452,6 +492,17 @@ struct hrn_ctx {
                 case OP_CONV: {
                     const ConvOp &cv = convs[op.idx];
                     const Tensor &ti = tensors[cv.in_t], &to = tensors[cv.out_t];
+                    if (cv.algo == 1) {
+                        Conv3Args a;
+                        a.in = row0(cv.in_t), a.out = row0(cv.out_t);
+                        a.w = blob + cv.w_off, a.bias = (const float *)(blob + cv.b_off);
+                        a.res = cv.res_t >= 0 ? row0(cv.res_t) : nullptr;
+                        a.cin = cv.cin, a.cout = cv.cout;
+                        a.h = to.h, a.wd = to.w, a.wp = to.wp, a.hpwp = to.hpwp;
+                        a.m = nb * to.hpwp, a.relu = cv.relu, a.slices = cv.slices, a.ntiles = cv.ntiles;
+                        e = launch_conv3x3_lds(a, cv.ks, cv.nr, conv3_variant, s);
+                        break;
+                    }
                     ConvArgs a;
                     a.in = row0(cv.in_t), a.out = row0(cv.out_t);
                     a.w = blob + cv.w_off, a.bias = (const float *)(blob + cv.b_off);
@@ -644,7 +695,7 @@ int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out) {
     out->has_residual = cv.res_t >= 0;
     out->in_h = h->tensors[cv.in_t].h, out->in_w = h->tensors[cv.in_t].w;
     out->out_h = h->tensors[cv.out_t].h, out->out_w = h->tensors[cv.out_t].w;
-    out->kpad = cv.kpad, out->nr = cv.nr;
+    out->kpad = cv.kpad, out->nr = cv.nr, out->algo = cv.algo, out->ks = cv.ks;
     out->w_offset = cv.w_off, out->w_bytes = cv.w_bytes, out->b_offset = cv.b_off;
     out->flops = cv.flops;
     return 0;

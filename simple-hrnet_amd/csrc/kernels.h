@@ -27,6 +27,21 @@ struct ConvArgs {
     int kchunks;                            // padded K / (32 bf16 | 16 f32)
 };
 
+// LDS-staged 3x3 stride-1 convolution (conv3x3_lds.hip); input and output share one geometry.
+struct Conv3Args {
+    const void *in;
+    void *out;
+    const void *w;      // slice-major packed weights: [cout tile][slice][chunk][frag][lane][16 B]
+    const float *bias;
+    const void *res;
+    int cin, cout;
+    int h, wd, wp, hpwp;
+    int m;              // rows to produce = n * hpwp
+    int relu;
+    int slices;         // cin / KS
+    int ntiles;         // cout / (16*NRB)
+};
+
 struct StemArgs {          // conv1 3->64 3x3 s2 + BN + ReLU, NCHW fp32 in, flat padded out
     const float *images;   // (n,3,H,W)
     void *out;
@@ -69,6 +84,7 @@ struct DecodeArgs {        // SimpleHRNet.py:297-308
 };
 
 hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s);
+hipError_t launch_conv3x3_lds(const Conv3Args &a, int ks, int nrb, int variant, hipStream_t s);
 hipError_t launch_stem(int dtype, const StemArgs &a, hipStream_t s);
 hipError_t launch_fuse(int dtype, const FuseArgs &a, hipStream_t s);
 hipError_t launch_head(int dtype, const HeadArgs &a, hipStream_t s);

@@ -62,8 +62,38 @@ def test_bad_arguments_raise():
     net.close()
 
 
+def _unpack_lds(net, info):
+    """inverse of the slice-major image of the LDS-staged 3x3 kernel:
+    [cout tile][slice][chunk][frag][lane][8 bf16], k_local = tap*ks + ci_local per slice"""
+    raw = net.read_blob(info.w_offset, info.w_bytes)
+    vals = (raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+    ks, nrb = info.ks, info.nr
+    slices, ntiles, nch = info.cin // ks, info.cout // (16 * nrb), (9 * ks + 31) // 32
+    vals = vals.reshape(ntiles, slices, nch, nrb, 64, 8)
+    out = np.zeros((info.cout, 9 * info.cin), np.float32)
+    pad = []
+    for t in range(ntiles):
+        for s in range(slices):
+            for c in range(nch):
+                for j in range(nrb):
+                    for lane in range(64):
+                        li, g = lane & 15, lane >> 4
+                        co = t * 16 * nrb + (li >> 2) * 4 * nrb + j * 4 + (li & 3)
+                        for e in range(8):
+                            kl = 32 * c + 8 * g + e
+                            v = vals[t, s, c, j, lane, e]
+                            if kl < 9 * ks:
+                                out[co, (kl // ks) * info.cin + s * ks + kl % ks] = v
+                            else:
+                                pad.append(v)
+    assert not np.any(pad)
+    return out
+
+
 def _unpack(net, info, dtype):
     """inverse of the documented fragment-major layout"""
+    if info.algo == 1:
+        return _unpack_lds(net, info)
     kc, vec = (32, 8) if dtype == "bf16" else (16, 4)
     raw = net.read_blob(info.w_offset, info.w_bytes)
     if dtype == "bf16":
@@ -96,7 +126,7 @@ def test_fold_and_pack(dtype):
     net = pkg.NativeHRNet(c, 17, (64, 64), dtype, max_batch=1, device=-1).load_state_dict(sd)
     infos = {i.name.decode(): i for i in net.conv_infos()}
     cases = [("conv2", "bn2"), ("layer1.0.conv1", "layer1.0.bn1"), ("transition1.0.0", "transition1.0.1"),
-             ("stage3.1.branches.2.3.conv2", "stage3.1.branches.2.3.bn2"),
+             ("stage3.1.branches.1.3.conv2", "stage3.1.branches.1.3.bn2"),
              ("stage4.0.fuse_layers.3.0.2.0", "stage4.0.fuse_layers.3.0.2.1"),
              ("stage4.2.fuse_layers.0.3.0", "stage4.2.fuse_layers.0.3.1")]
     for conv, bn in cases:
