@@ -1,24 +1,31 @@
-// 3x3 / stride-1 / pad-1 convolution (the BasicBlock convs = 84 % of HRNet-W48 FLOPs) as an LDS-staged
-// implicit GEMM on bf16 MFMA, written for gfx950.
+// 3x3 / stride-1 / pad-1 convolution (the BasicBlock convs = 84 % of HRNet-W48 FLOPs) as an LDS-staged,
+// software-pipelined implicit GEMM on bf16 MFMA, written for gfx950.
 //
-// The flat padded NHWC layout turns the nine taps into nine constant row shifts of ONE
-// activation matrix, so a block stages a single contiguous "slab" of rows
-//     [p0 - (Wp+1), p0 + BM + (Wp+1))  x  KS input channels
-// in LDS and serves all nine taps of that channel slice from it: the activations cross L2->LDS once per
-// slice instead of nine times.  KS = 48 gives a 96-byte LDS row pitch; 96 = 32 (mod 64) makes the 16-lane
-// ds_read_b128 groups (16 consecutive pixels x two 16-byte k-groups) hit all 64 banks exactly once, so the
-// natural (unswizzled, unpadded) image is conflict-free and can be written by global_load_lds (LDS-DMA,
-// lane-linear destination) with no staging registers.  Weights of the (cout tile, slice) arrive the same way
-// from a pre-packed fragment-major image (pack_conv_lds in hrnet_mi355.cpp): a linear copy.
-//
-// K is flattened per slice: k = tap*KS + ci, cut into 32-wide MFMA chunks (KS=48: 432 -> 14 chunks, the last
-// one half zero-padded, 3.6 % waste; the 16x16x16 MFMA that would avoid the padding issues at the same
-// 16 cycles as 16x16x32 on gfx950 -- measured, tools/mfma_rate.hip).  A chunk's four 8-wide k-groups may
-// belong to different taps; groups (0,1) and (2,3) never straddle a tap, which keeps the bank pattern.
-//
-// Tile: block = WAVES waves, wave = 16*MR pixels x 16*NRB couts (operands swapped, D = W * X^T, so a lane
-// owns 4*NRB contiguous channels of one pixel -> the same wide-store epilogue as the generic kernel).
-// Occupancy plan: LDS <= 80 KiB per block -> 2 blocks / CU, one loading while the other computes.
+// Data movement
+//   * The flat padded NHWC layout turns the nine taps into nine constant row shifts of ONE
+//     activation matrix, so a block stages a single contiguous "slab" of rows
+//         [p0 - (Wp+1), p0 + BM + (Wp+1))  x  KS input channels
+//     in LDS and serves all nine taps of that channel slice from it (activations cross L2->LDS once per
+//     slice, not nine times).  KS = 48 -> 96-byte LDS row pitch; 96 = 32 (mod 64) makes each 16-lane
+//     ds_read_b128 group (16 consecutive pixels x two 16-byte k-groups) cover all 64 banks exactly once, so
+//     the natural, unswizzled image is conflict-free and is written by global_load_lds (LDS-DMA) directly.
+//   * Weights of (cout tile, slice) come from a pre-packed fragment-major image (pack_conv_lds in
+//     hrnet_mi355.cpp): a linear LDS-DMA copy, read back with lane*16 addressing.
+//   * K is flattened per slice, k = tap*KS + ci, in 32-wide MFMA chunks: 432 -> 14 chunks (last one half
+//     zero; the 16x16x16 MFMA that would avoid the padding costs the same 16 cycles on gfx950 -- measured).
+// Pipeline (one block per CU, 8 waves = 2 per SIMD, persistent over `tiles_per_block` M tiles)
+//   * unit of work = half a slice (7 chunks).  LDS holds two weight half-buffers (2 x 21 KiB) and two slab
+//     buffers (2 x 56 KiB).  At the top of half-stage h every wave waits for its own LDS-DMA (vmcnt 0), the
+//     block meets at ONE barrier, the loads of half-stage h+1 (next weight half; next slab when a new slice
+//     or tile starts) are issued, then half-stage h is computed -- so every load has a full compute phase
+//     (>= 1344 MFMA cycles) to land, also across tile boundaries and under the epilogue.
+//   * single-slice problems (cin == 48) keep both weight halves resident across tiles.
+//   * an LDS-DMA instruction costs its wave ~100+ issue cycles and the epilogue is store-latency bound, so
+//     two waves share each SIMD: while one issues loads / stores, the other keeps the MFMA pipe busy.
+//     The residual tile is requested before the last half-stage's MFMAs and is in registers by the epilogue.
+// Tile: wave = 16*MR pixels x 48 couts (MR = 4: BM = 512, MR = 2: BM = 256 for the 96x72 branch whose halo
+// would not fit twice); operands swapped (D = W * X^T) so a lane owns 12 contiguous channels of one pixel.
+// One launch covers a GROUP of independent convolutions (the k-th conv of every branch of a stage module).
 #include "kernels.h"
 
 namespace hrn {
@@ -41,140 +48,271 @@ __device__ __forceinline__ void glds16(const void *gsrc, char *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int KS, int NRB, int MR, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, (WAVES >= 4 ? 2 : 1)) void conv3x3_lds_kernel(const Conv3Args p) {
-    constexpr int NCH = (9 * KS + 31) / 32;        // MFMA K-chunks per slice
-    constexpr int ROWB = KS * 2;                   // LDS row pitch in bytes
-    constexpr int UPR = KS / 8;                    // 16-byte units per slab row
-    constexpr int BM = WAVES * 16 * MR;
-    constexpr int WBYTES = NCH * NRB * 1024;
-    constexpr int NT = WAVES * 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *wlds = smem;
-    char *slab = smem + WBYTES;
+constexpr int C3_KS = 48, C3_NRB = 3, C3_NCH = 14, C3_HCH = 7;   // chunks per slice / per half
+constexpr int C3_WHALF = C3_HCH * C3_NRB * 1024;                 // 21504 B
+constexpr int C3_SLAB = 57344;                                   // one slab buffer (>= (512+2*37+2)*96)
+constexpr int C3_LDS = 2 * C3_WHALF + 2 * C3_SLAB;               // 157696 B
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef HRN_C3_TIMING
+#define C3_T(x) const long long x = __builtin_amdgcn_s_memtime()
+__device__ long long *g_c3_timing = nullptr;
+#else
+#define C3_T(x)
+#endif
+
+template <int MR>
+__device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, const int mt0, const int nb,
+                                          char *smem) {
+    constexpr int KS = C3_KS, NRB = C3_NRB, ROWB = KS * 2, UPR = KS / 8, NT = 512;
+    constexpr int BM = 128 * MR;
+    constexpr int SLAB_ITERS = C3_SLAB / 16 / NT;  // max LDS-DMA instructions per wave per slab (7)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, SALU M0
     const int li = lane & 15, g = lane >> 4;
-    const int nt = blockIdx.x % p.ntiles, mt = blockIdx.x / p.ntiles;
-    const int p0 = mt * BM;
-    const int slab_rows = BM + 2 * p.wp + 2;
-    const int slab_units = slab_rows * UPR;
+    const int m = nb * p.hpwp;
+    const int mtiles = (m + BM - 1) / BM;
+    int ntile = mtiles - mt0;
+    if (ntile > p.tiles_per_block) ntile = p.tiles_per_block;
+    if (ntile <= 0) return;
+    const int S = p.slices;
+    const int slab_units = (BM + 2 * p.wp + 2) * UPR;
     const unsigned short *__restrict__ in = (const unsigned short *)p.in;
+    char *const wbuf = smem;
+    char *const sbuf = smem + 2 * C3_WHALF;
 
     // per-lane LDS byte offset of k-group g of chunk c, relative to the lane's own pixel row in the slab
-    int xoff[NCH];
+    int xoff[C3_NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int c = 0; c < C3_NCH; ++c) {
         int k0 = 32 * c + 8 * g;
         if (k0 >= 9 * KS) k0 = 0;  // zero-weight padding: any valid slab address
         const int tap = k0 / KS, ci = k0 - tap * KS;
         const int dh = tap / 3, dw = tap - 3 * dh;
         xoff[c] = (dh * p.wp + dw) * ROWB + ci * 2;
     }
-    int xrow[MR];
+    const int xrow0 = (wave * 16 * MR + li) * ROWB;
+    // per-lane element offset of the k-th slab LDS-DMA piece relative to the slab's first row
+    unsigned srel[SLAB_ITERS];
 #pragma unroll
-    for (int i = 0; i < MR; ++i) xrow[i] = (wave * 16 * MR + i * 16 + li) * ROWB;
-
-    f32x4 acc[MR][NRB];
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const long slab_row0 = (long)p0 - p.wp - 1;  // first staged activation row (guard rows make it valid)
-    for (int s = 0; s < p.slices; ++s) {
-        if (s) __syncthreads();  // everybody done reading the previous slice
-        // ---- stage weights of (cout tile nt, slice s): linear copy of the pre-packed image
-        const char *wsrc = (const char *)p.w + ((size_t)nt * p.slices + s) * WBYTES;
-        for (int u0 = wave * 64; u0 < WBYTES / 16; u0 += NT) glds16(wsrc + (size_t)(u0 + lane) * 16, wlds + u0 * 16);
-        // ---- stage the activation slab: rows of KS channels (UPR units each) from rows of cin channels
-        for (int u0 = wave * 64; u0 < slab_units; u0 += NT) {
-            int u = u0 + lane;
-            if (u >= slab_units) u = slab_units - 1;  // tail lanes re-read a valid unit; LDS has room for them
-            const int r = u / UPR, q = u - r * UPR;
-            glds16(in + (slab_row0 + r) * p.cin + s * KS + q * 8, slab + u0 * 16);
-        }
-        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): LDS-DMA data of this wave has landed
-        __syncthreads();
-        // ---- 9 taps x KS channels as NCH chunks of K = 32
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            s16x8 wf[NRB];
-#pragma unroll
-            for (int j = 0; j < NRB; ++j) wf[j] = *(const s16x8 *)(wlds + (c * NRB + j) * 1024 + lane * 16);
-            s16x8 xf[MR];
-#pragma unroll
-            for (int i = 0; i < MR; ++i) xf[i] = *(const s16x8 *)(slab + xrow[i] + xoff[c]);
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-#pragma unroll
-                for (int j = 0; j < NRB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]),
-                                                                        __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0,
-                                                                        0, 0);
-        }
+    for (int k = 0; k < SLAB_ITERS; ++k) {
+        int u = k * NT + tid;
+        if (u >= slab_units) u = slab_units - 1;  // tail lanes re-read a valid unit; LDS has room for them
+        const int r = u / UPR, q = u - r * UPR;
+        srel[k] = (unsigned)(r * p.cin + q * 8) * 2u;  // bytes
     }
 
-    // ---- epilogue: + bias (+ residual) (ReLU), zero on pad pixels; lane owns 4*NRB contiguous channels
     const int ch0 = nt * 16 * NRB + g * 4 * NRB;
     float bias[4 * NRB];
 #pragma unroll
     for (int c = 0; c < 4 * NRB; ++c) bias[c] = p.bias[ch0 + c];
     unsigned short *__restrict__ out = (unsigned short *)p.out;
     const unsigned short *__restrict__ res = (const unsigned short *)p.res;
-#pragma unroll
-    for (int i = 0; i < MR; ++i) {
-        const int q = p0 + wave * 16 * MR + i * 16 + li;
-        if (q >= p.m) continue;
-        const int rem = q % p.hpwp;
-        const int ho = rem / p.wp, wo = rem - ho * p.wp;
-        const bool ok = (ho < p.h) && (wo < p.wd);
-        const size_t o = (size_t)q * p.cout + ch0;
-#pragma unroll
-        for (int j = 0; j < NRB; ++j) {
-            s16x4 r4 = {};
-            if (res) r4 = *(const s16x4 *)(res + o + j * 4);
-            s16x4 o4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r] + bias[j * 4 + r];
-                if (res) v += bf2f((unsigned short)r4[r]);
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (!ok) v = 0.f;
-                o4[r] = (short)f2bf(v);
-            }
-            *(s16x4 *)(out + o + j * 4) = o4;
+    const char *const wsrc_nt = (const char *)p.w + (size_t)nt * S * (2 * C3_WHALF);
+
+    // The LDS-DMA of half-stage (tt, s, hf) is cut into per-wave "pieces" (one 1 KiB instruction each):
+    // pieces 0..2 = this wave's share of the weight half -> wbuf[hf]; pieces 3..9 = its share of the slab of
+    // (tile tt, slice s) -> sbuf[par] (only when hf == 0).  A piece costs its wave ~150 issue cycles, so they
+    // are spread over the chunk loop of the half-stage that runs meanwhile (the SIMD partner's MFMAs cover it).
+    struct Next {
+        const char *wsrc;   // nullptr: weights stay resident
+        char *wdst;
+        const char *ssrc;   // nullptr: no slab in this half-stage
+        char *sdst;
+    };
+    auto plan = [&](int tt, int s, int hf, int par) {
+        Next n;
+        n.wsrc = (S > 1 || tt == 0) ? wsrc_nt + (size_t)(2 * s + hf) * C3_WHALF : nullptr;
+        n.wdst = wbuf + hf * C3_WHALF;
+        n.ssrc = nullptr;
+        n.sdst = sbuf + par * C3_SLAB + wave * 1024;
+        if (hf == 0) {
+            const long row0 = (long)(mt0 + tt) * BM - p.wp - 1;  // guard rows make negative / overrun rows valid
+            n.ssrc = (const char *)(in + row0 * p.cin + s * KS);
         }
+        return n;
+    };
+    auto piece = [&](const Next &n, int idx) {
+        if (idx < 3) {
+            const int u0 = idx * NT + wave * 64;
+            if (n.wsrc && u0 < C3_WHALF / 16) glds16(n.wsrc + (size_t)(u0 + lane) * 16, n.wdst + u0 * 16);
+        } else {
+            const int k = idx - 3;
+            if (n.ssrc && k * NT + wave * 64 < slab_units) glds16(n.ssrc + srel[k], n.sdst + k * NT * 16);
+        }
+    };
+    constexpr int NPIECE = 3 + SLAB_ITERS;
+
+    f32x4 acc[MR][NRB];
+    s16x4 rpre[MR][NRB];
+    int slab_par = 0;
+#ifdef HRN_C3_TIMING
+    long long t_wait = 0, t_issue = 0, t_comp = 0, t_epi = 0;
+    int n_half = 0;
+    C3_T(t_begin);
+#endif
+    {
+        const Next n0 = plan(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NPIECE; ++k) piece(n0, k);
     }
+    for (int tt = 0; tt < ntile; ++tt) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                C3_T(tA);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed
+                __syncthreads();  // everyone's has; everyone is done reading the buffers refilled below
+                C3_T(tB);
+                // ---- what the next half-stage needs (issued piecewise inside the chunk loop below)
+                Next nx;
+                if (hf == 0) {
+                    nx = plan(tt, s, 1, slab_par);  // weights only
+                } else {
+                    int s2 = s + 1, t2 = tt;
+                    if (s2 == S) s2 = 0, ++t2;
+                    nx = plan(t2, s2, 0, slab_par ^ 1);
+                    if (t2 >= ntile) nx.wsrc = nullptr, nx.ssrc = nullptr;
+                }
+                // ---- last half-stage of the tile: request the residual tile now, it lands under the MFMAs
+                if (hf == 1 && s == S - 1) {
+                    const int p0r = (mt0 + tt) * BM + wave * 16 * MR + li;
+#pragma unroll
+                    for (int i = 0; i < MR; ++i) {
+                        int q = p0r + i * 16;
+                        if (q >= m) q = 0;
+                        const size_t o = (size_t)q * p.cout + ch0;
+#pragma unroll
+                        for (int j = 0; j < NRB; ++j) rpre[i][j] = res ? *(const s16x4 *)(res + o + j * 4) : s16x4{};
+                    }
+                }
+                C3_T(tC);
+                // ---- compute 7 chunks of K = 32 from wbuf[hf] and the current slab
+                const char *wl = wbuf + hf * C3_WHALF + lane * 16;
+                const char *sl = sbuf + slab_par * C3_SLAB + xrow0;
+                // explicit register double-buffering: the fragments of chunk c+1 are requested before the
+                // MFMAs of chunk c issue (one wave per SIMD: nothing else hides the LDS latency)
+                s16x8 wf[2][NRB], xf[2][MR];
+#pragma unroll
+                for (int j = 0; j < NRB; ++j) wf[0][j] = *(const s16x8 *)(wl + j * 1024);
+#pragma unroll
+                for (int i = 0; i < MR; ++i) xf[0][i] = *(const s16x8 *)(sl + i * 16 * ROWB + xoff[hf * C3_HCH]);
+#pragma unroll
+                for (int c = 0; c < C3_HCH; ++c) {
+                    const int cur = c & 1, nxt = cur ^ 1;
+                    if (c + 1 < C3_HCH) {
+#pragma unroll
+                        for (int j = 0; j < NRB; ++j) wf[nxt][j] = *(const s16x8 *)(wl + ((c + 1) * NRB + j) * 1024);
+#pragma unroll
+                        for (int i = 0; i < MR; ++i)
+                            xf[nxt][i] = *(const s16x8 *)(sl + i * 16 * ROWB + xoff[hf * C3_HCH + c + 1]);
+                    }
+                    piece(nx, c);
+                    if (c + C3_HCH < NPIECE) piece(nx, c + C3_HCH);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this chunk's MFMAs
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+#pragma unroll
+                        for (int j = 0; j < NRB; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, wf[cur][j]), __builtin_bit_cast(bf16x8, xf[cur][i]),
+                                acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#ifdef HRN_C3_TIMING
+                C3_T(tD);
+                t_wait += tB - tA, t_issue += tC - tB, t_comp += tD - tC, ++n_half;
+#endif
+                if (hf == 1) slab_par ^= 1;
+            }
+        }
+        // ---- epilogue: + bias (+ residual) (ReLU), zero on pad pixels; lane owns 12 contiguous channels
+        C3_T(tE);
+        const int p0 = (mt0 + tt) * BM;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            const int q = p0 + wave * 16 * MR + i * 16 + li;
+            if (q >= m) continue;
+            const int n_img = (int)(((unsigned long long)(unsigned)q * p.magic_hpwp) >> p.shift_hpwp);
+            const int rem = q - n_img * p.hpwp;
+            const int ho = (int)(((unsigned long long)(unsigned)rem * p.magic_wp) >> p.shift_wp);
+            const int wo = rem - ho * p.wp;
+            const bool ok = (ho < p.h) && (wo < p.wd);
+            const size_t o = (size_t)q * p.cout + ch0;
+#pragma unroll
+            for (int j = 0; j < NRB; ++j) {
+                const s16x4 r4 = rpre[i][j];
+                s16x4 o4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bias[j * 4 + r] + bf2f((unsigned short)r4[r]);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (!ok) v = 0.f;
+                    o4[r] = (short)f2bf(v);
+                }
+                *(s16x4 *)(out + o + j * 4) = o4;
+            }
+        }
+#ifdef HRN_C3_TIMING
+        C3_T(tF);
+        t_epi += tF - tE;
+#endif
+    }
+#ifdef HRN_C3_TIMING
+    if (tid == 0 && g_c3_timing) {
+        C3_T(t_end);
+        long long *o = g_c3_timing + (size_t)blockIdx.x * 8;
+        o[0] = t_wait, o[1] = t_issue, o[2] = t_comp, o[3] = t_epi, o[4] = t_end - t_begin, o[5] = n_half, o[6] = MR,
+        o[7] = S;
+    }
+#endif
 }
 
-template <int KS, int NRB, int MR, int WAVES>
-static hipError_t launch_t(const Conv3Args &a, hipStream_t s) {
-    constexpr int NCH = (9 * KS + 31) / 32;
-    constexpr int BM = WAVES * 16 * MR;
-    const int slab_rows = BM + 2 * a.wp + 2;
-    size_t shm = (size_t)NCH * NRB * 1024 + (((size_t)slab_rows * (KS / 8) + 63) / 64) * 1024;
+__global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem *__restrict__ probs,
+                                                             const int2 *__restrict__ blockmap, const int nb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int2 bm = blockmap[blockIdx.x];
+    const Conv3Problem p = probs[bm.x & 0xff];
+    if (p.bm == 512)
+        conv3_run<4>(p, bm.x >> 8, bm.y, nb, smem);
+    else
+        conv3_run<2>(p, bm.x >> 8, bm.y, nb, smem);
+}
+
+#ifdef HRN_C3_TIMING
+// debug: per-block phase cycle counters of the most recent launch (tools/c3_timing.py)
+extern "C" int hrn_debug_c3_timing(long long *host_out, int max_blocks) {
+    static long long *buf = nullptr;
+    if (!buf) {
+        if (hipMalloc((void **)&buf, (size_t)max_blocks * 64) != hipSuccess) return -1;
+        (void)hipMemset(buf, 0, (size_t)max_blocks * 64);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_c3_timing), &buf, sizeof(buf));
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host_out, buf, (size_t)max_blocks * 64, hipMemcpyDeviceToHost);
+    return 1;
+}
+#endif
+
+int conv3x3_lds_bm(int wp) { return (512 + 2 * wp + 2) * 96 <= C3_SLAB ? 512 : 256; }
+
+hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb,
+                              hipStream_t s) {
+    if (nblocks <= 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv3x3_lds_kernel<KS, NRB, MR, WAVES>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)conv3x3_lds_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int mtiles = (a.m + BM - 1) / BM;
-    hipLaunchKernelGGL((conv3x3_lds_kernel<KS, NRB, MR, WAVES>), dim3(mtiles * a.ntiles), dim3(WAVES * 64), shm, s, a);
+    hipLaunchKernelGGL(conv3x3_lds_kernel, dim3(nblocks), dim3(512), C3_LDS, s, probs_dev, (const int2 *)blockmap_dev,
+                       nb);
     return hipGetLastError();
-}
-
-int conv3x3_lds_block_rows(int variant) { return variant == 1 ? 256 : 256; }
-
-hipError_t launch_conv3x3_lds(const Conv3Args &a, int ks, int nrb, int variant, hipStream_t s) {
-    if (a.m <= 0) return hipSuccess;
-    if (ks == 48 && nrb == 3) {
-        if (variant == 1) return launch_t<48, 3, 8, 2>(a, s);   // 2 waves x 128 px
-        return launch_t<48, 3, 4, 4>(a, s);                     // 4 waves x 64 px
-    }
-    return hipErrorInvalidValue;
 }
 
 }  // namespace hrn

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -36,7 +37,7 @@ struct Buffer {
     bool in_use = false;
 };
 
-enum OpKind { OP_STEM, OP_CONV, OP_FUSE, OP_HEAD, OP_DECODE };
+enum OpKind { OP_STEM, OP_CONV, OP_CONV3_GROUP, OP_FUSE, OP_HEAD, OP_DECODE };
 
 struct ConvOp {
     std::string conv, bn;  // state_dict prefixes ("" bn => plain bias conv)
@@ -47,6 +48,18 @@ struct ConvOp {
     int ks = 0, slices = 0, ntiles = 0, nch = 0;
     int64_t w_off = 0, w_bytes = 0, b_off = 0;
     double flops = 0;
+};
+
+// a set of independent LDS-staged 3x3 convolutions issued as ONE launch (conv3x3_lds.hip)
+struct Conv3Group {
+    std::vector<int> conv_idx;
+    int prob_first = 0;          // index of the group's first descriptor in the device array
+    int max_wp = 0;
+    int64_t map_capacity = 0;    // blocks at max_batch
+    int2 *map_dev = nullptr;
+    std::vector<int2> map_host;
+    int cached_nb = -1;
+    int nblocks = 0;
 };
 
 struct FuseOp {
@@ -60,6 +73,14 @@ struct Op {
     OpKind kind;
     int idx;  // index into convs / fuses
 };
+
+// x / d == (x * magic) >> shift for 0 <= x < 2^27
+inline void fast_div(int d, unsigned *magic, int *shift) {
+    int l = 0;
+    while ((1 << l) < d) ++l;
+    *shift = 30 + l;
+    *magic = (unsigned)((1ull << *shift) / (unsigned)d + 1);
+}
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -82,6 +103,8 @@ struct hrn_ctx {
     std::vector<Buffer> buffers;
     std::vector<ConvOp> convs;
     std::vector<FuseOp> fuses;
+    std::vector<Conv3Group> groups;
+    Conv3Problem *probs_dev = nullptr;
     std::vector<Op> ops;
     int stem_out_t = -1, head_in_t = -1;
     int64_t stem_w_off = 0, stem_b_off = 0, head_w_off = 0, head_b_off = 0;
@@ -91,7 +114,8 @@ struct hrn_ctx {
     bool weights_loaded = false;
 
     bool disable_lds = getenv("HRN_DISABLE_LDS") != nullptr;
-    int conv3_variant = getenv("HRN_CONV3_VARIANT") ? atoi(getenv("HRN_CONV3_VARIANT")) : 0;
+    bool disable_group = getenv("HRN_DISABLE_GROUP") != nullptr;
+    int half_stages_per_block = getenv("HRN_HALF_STAGES") ? atoi(getenv("HRN_HALF_STAGES")) : 16;
     int head_slabs = 1, head_slab_px = 1024;
     float *part_val = nullptr;
     int *part_idx = nullptr;
@@ -123,7 +147,7 @@ struct hrn_ctx {
     void release(int t) { buffers[tensors[t].buf].in_use = false; }
 
     int add_conv(const std::string &conv, const std::string &bn, int in_t, int cout, int k, int stride, int relu,
-                 int res_t = -1) {
+                 int res_t = -1, bool emit = true) {
         const Tensor &ti = tensors[in_t];
         ConvOp op;
         op.conv = conv, op.bn = bn, op.in_t = in_t, op.res_t = res_t;
@@ -142,8 +166,32 @@ struct hrn_ctx {
             op.kpad = op.nch * 32 * op.slices;
         }
         convs.push_back(op);
-        ops.push_back({OP_CONV, (int)convs.size() - 1});
+        if (emit) ops.push_back({OP_CONV, (int)convs.size() - 1});
         return op.out_t;
+    }
+
+    // emit a set of mutually independent convolutions: one grouped launch when all of them run on the
+    // LDS-staged kernel, individual launches otherwise
+    void emit_convs(const std::vector<int> &idx) {
+        std::vector<int> lds;
+        for (int i : idx) {
+            if (convs[i].algo == 1)
+                lds.push_back(i);
+            else
+                ops.push_back({OP_CONV, i});
+        }
+        if (lds.empty()) return;
+        std::vector<std::vector<int>> sets;
+        if (disable_group)
+            for (int i : lds) sets.push_back({i});
+        else
+            sets.push_back(lds);
+        for (auto &set : sets) {
+            Conv3Group g;
+            g.conv_idx = set;
+            groups.push_back(g);
+            ops.push_back({OP_CONV3_GROUP, (int)groups.size() - 1});
+        }
     }
 
     int add_fuse(const std::vector<int> &terms, const std::vector<int> &shifts) {
@@ -167,17 +215,27 @@ struct hrn_ctx {
     void add_stage(const std::string &name, std::vector<int> &xs, int nout) {
         const int nb = (int)xs.size();
         char buf[160];
-        for (int b = 0; b < nb; ++b) {
-            const int w = c << b;
-            for (int k = 0; k < 4; ++k) {  // BasicBlock, modules.py:56-72
+        // BasicBlock x4 per branch (modules.py:56-72); the branches are independent until the fuse, so the
+        // k-th conv1 (then conv2) of every branch goes out as one grouped launch
+        for (int k = 0; k < 4; ++k) {
+            std::vector<int> t1(nb), g1, g2;
+            for (int b = 0; b < nb; ++b) {
                 snprintf(buf, sizeof buf, "%s.branches.%d.%d", name.c_str(), b, k);
                 const std::string p = buf;
-                const int t1 = add_conv(p + ".conv1", p + ".bn1", xs[b], w, 3, 1, 1);
-                const int t2 = add_conv(p + ".conv2", p + ".bn2", t1, w, 3, 1, 1, xs[b]);
-                release(t1);
+                t1[b] = add_conv(p + ".conv1", p + ".bn1", xs[b], c << b, 3, 1, 1, -1, false);
+                g1.push_back((int)convs.size() - 1);
+            }
+            emit_convs(g1);
+            for (int b = 0; b < nb; ++b) {
+                snprintf(buf, sizeof buf, "%s.branches.%d.%d", name.c_str(), b, k);
+                const std::string p = buf;
+                const int t2 = add_conv(p + ".conv2", p + ".bn2", t1[b], c << b, 3, 1, 1, xs[b], false);
+                g2.push_back((int)convs.size() - 1);
+                release(t1[b]);
                 release(xs[b]);
                 xs[b] = t2;
             }
+            emit_convs(g2);
         }
         std::vector<int> outs;
         for (int i = 0; i < nout; ++i) {
@@ -294,9 +352,79 @@ struct hrn_ctx {
         }
         if (!hip_ok(hipMalloc((void **)&blob, (size_t)blob_bytes), "hipMalloc(weights)")) return false;
         if (!hip_ok(hipMemset(blob, 0, (size_t)blob_bytes), "hipMemset(weights)")) return false;
+        if (!setup_groups()) return false;
         if (!hip_ok(hipMalloc((void **)&part_val, (size_t)part * 4), "hipMalloc(part_val)")) return false;
         if (!hip_ok(hipMalloc((void **)&part_idx, (size_t)part * 4), "hipMalloc(part_idx)")) return false;
         return hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    }
+
+    // every block walks ~`half_stages_per_block` half-slices so that blocks of all branches last alike
+    int conv3_tiles_per_block(const ConvOp &cv) const {
+        const int t = half_stages_per_block / (2 * cv.slices);
+        return t < 1 ? 1 : t;
+    }
+
+    // device-resident descriptors + block maps of the grouped conv launches
+    int group_blocks(const Conv3Group &g, int nb, std::vector<int2> *out) const {
+        struct Ent {
+            double key;
+            int2 v;
+        };
+        std::vector<Ent> ents;
+        for (size_t k = 0; k < g.conv_idx.size(); ++k) {
+            const ConvOp &cv = convs[g.conv_idx[k]];
+            const Tensor &to = tensors[cv.out_t];
+            const int bm = conv3x3_lds_bm(to.wp);
+            const int mtiles = (nb * to.hpwp + bm - 1) / bm;
+            const int tpb = conv3_tiles_per_block(cv);
+            const int mgroups = (mtiles + tpb - 1) / tpb;
+            const int total = mgroups * cv.ntiles;
+            for (int i = 0; i < total; ++i) {
+                const int mg = i / cv.ntiles, nt = i % cv.ntiles;
+                ents.push_back({(i + 0.5) / total, int2{(int)k | (nt << 8), mg * tpb}});
+            }
+        }
+        std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
+        if (out) {
+            out->resize(ents.size());
+            for (size_t i = 0; i < ents.size(); ++i) (*out)[i] = ents[i].v;
+        }
+        return (int)ents.size();
+    }
+
+    bool setup_groups() {
+        size_t nprob = 0;
+        for (auto &g : groups) {
+            g.prob_first = (int)nprob;
+            nprob += g.conv_idx.size();
+        }
+        if (!nprob) return true;
+        std::vector<Conv3Problem> hp(nprob);
+        for (auto &g : groups) {
+            g.max_wp = 0;
+            for (size_t k = 0; k < g.conv_idx.size(); ++k) {
+                const ConvOp &cv = convs[g.conv_idx[k]];
+                const Tensor &to = tensors[cv.out_t];
+                Conv3Problem &q = hp[g.prob_first + k];
+                q.in = row0(cv.in_t), q.out = row0(cv.out_t);
+                q.w = blob + cv.w_off, q.bias = (const float *)(blob + cv.b_off);
+                q.res = cv.res_t >= 0 ? row0(cv.res_t) : nullptr;
+                q.cin = cv.cin, q.cout = cv.cout, q.h = to.h, q.wd = to.w, q.wp = to.wp, q.hpwp = to.hpwp;
+                q.relu = cv.relu, q.slices = cv.slices, q.ntiles = cv.ntiles;
+                q.tiles_per_block = conv3_tiles_per_block(cv);
+                q.bm = conv3x3_lds_bm(to.wp);
+                fast_div(to.hpwp, &q.magic_hpwp, &q.shift_hpwp);
+                fast_div(to.wp, &q.magic_wp, &q.shift_wp);
+                if (to.wp > g.max_wp) g.max_wp = to.wp;
+            }
+            g.map_capacity = group_blocks(g, max_batch, nullptr);
+            if (!hip_ok(hipMalloc((void **)&g.map_dev, (size_t)g.map_capacity * sizeof(int2)), "hipMalloc(blockmap)"))
+                return false;
+            workspace_bytes += g.map_capacity * (int64_t)sizeof(int2);
+        }
+        if (!hip_ok(hipMalloc((void **)&probs_dev, nprob * sizeof(Conv3Problem)), "hipMalloc(problems)")) return false;
+        return hip_ok(hipMemcpy(probs_dev, hp.data(), nprob * sizeof(Conv3Problem), hipMemcpyHostToDevice),
+                      "hipMemcpy(problems)");
     }
 
     void free_all() {
@@ -309,6 +437,9 @@ struct hrn_ctx {
             if (blob) (void)hipFree(blob);
             if (part_val) (void)hipFree(part_val);
             if (part_idx) (void)hipFree(part_idx);
+            if (probs_dev) (void)hipFree(probs_dev);
+            for (auto &g : groups)
+                if (g.map_dev) (void)hipFree(g.map_dev);
         }
         blob = nullptr;
     }
@@ -492,17 +623,6 @@ struct hrn_ctx {
                 case OP_CONV: {
                     const ConvOp &cv = convs[op.idx];
                     const Tensor &ti = tensors[cv.in_t], &to = tensors[cv.out_t];
-                    if (cv.algo == 1) {
-                        Conv3Args a;
-                        a.in = row0(cv.in_t), a.out = row0(cv.out_t);
-                        a.w = blob + cv.w_off, a.bias = (const float *)(blob + cv.b_off);
-                        a.res = cv.res_t >= 0 ? row0(cv.res_t) : nullptr;
-                        a.cin = cv.cin, a.cout = cv.cout;
-                        a.h = to.h, a.wd = to.w, a.wp = to.wp, a.hpwp = to.hpwp;
-                        a.m = nb * to.hpwp, a.relu = cv.relu, a.slices = cv.slices, a.ntiles = cv.ntiles;
-                        e = launch_conv3x3_lds(a, cv.ks, cv.nr, conv3_variant, s);
-                        break;
-                    }
                     ConvArgs a;
                     a.in = row0(cv.in_t), a.out = row0(cv.out_t);
                     a.w = blob + cv.w_off, a.bias = (const float *)(blob + cv.b_off);
@@ -513,6 +633,18 @@ struct hrn_ctx {
                     a.m = nb * to.hpwp;
                     a.ksize = cv.k, a.stride = cv.stride, a.relu = cv.relu, a.kchunks = cv.kchunks;
                     e = launch_conv(dtype, a, cv.nr, s);
+                    break;
+                }
+                case OP_CONV3_GROUP: {
+                    Conv3Group &g = groups[op.idx];
+                    if (g.cached_nb != nb) {  // block map depends on the micro-batch size: rebuild on change
+                        g.nblocks = group_blocks(g, nb, &g.map_host);
+                        e = hipMemcpyAsync(g.map_dev, g.map_host.data(), (size_t)g.nblocks * sizeof(int2),
+                                           hipMemcpyHostToDevice, s);
+                        if (e != hipSuccess) break;
+                        g.cached_nb = nb;
+                    }
+                    e = launch_conv3x3_lds(probs_dev + g.prob_first, g.map_dev, g.nblocks, nb, s);
                     break;
                 }
                 case OP_FUSE: {
@@ -734,6 +866,12 @@ int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms
             const Op &op = h->ops[oi];
             if (op.kind == OP_CONV) {
                 if (conv_ms && op.idx < conv_ms_len) conv_ms[op.idx] = ms;
+            } else if (op.kind == OP_CONV3_GROUP) {  // one launch, several convs: split by FLOPs
+                const Conv3Group &g = h->groups[op.idx];
+                double tot = 0;
+                for (int ci : g.conv_idx) tot += h->convs[ci].flops;
+                for (int ci : g.conv_idx)
+                    if (conv_ms && ci < conv_ms_len) conv_ms[ci] = (float)(ms * h->convs[ci].flops / tot);
             } else if (other_ms) {
                 const int slot = op.kind == OP_STEM ? 0 : op.kind == OP_FUSE ? 1 : op.kind == OP_HEAD ? 2 : 3;
                 other_ms[slot] += ms;

@@ -28,7 +28,8 @@ struct ConvArgs {
 };
 
 // LDS-staged 3x3 stride-1 convolution (conv3x3_lds.hip); input and output share one geometry.
-struct Conv3Args {
+// One device-resident descriptor per convolution; a launch covers a group of them.
+struct Conv3Problem {
     const void *in;
     void *out;
     const void *w;      // slice-major packed weights: [cout tile][slice][chunk][frag][lane][16 B]
@@ -36,11 +37,16 @@ struct Conv3Args {
     const void *res;
     int cin, cout;
     int h, wd, wp, hpwp;
-    int m;              // rows to produce = n * hpwp
     int relu;
     int slices;         // cin / KS
     int ntiles;         // cout / (16*NRB)
+    int tiles_per_block;  // consecutive M tiles one block walks (weights stay in LDS when slices == 1)
+    int bm;               // pixels per M tile: 512, or 256 when two 512-row slabs would not fit in LDS
+    // x / d == (x * magic) >> shift for x < 2^27, magic = floor(2^shift / d) + 1, shift = 30 + ceil(log2 d)
+    unsigned magic_hpwp, magic_wp;
+    int shift_hpwp, shift_wp;
 };
+int conv3x3_lds_bm(int wp);
 
 struct StemArgs {          // conv1 3->64 3x3 s2 + BN + ReLU, NCHW fp32 in, flat padded out
     const float *images;   // (n,3,H,W)
@@ -84,13 +90,14 @@ struct DecodeArgs {        // SimpleHRNet.py:297-308
 };
 
 hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s);
-hipError_t launch_conv3x3_lds(const Conv3Args &a, int ks, int nrb, int variant, hipStream_t s);
+hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb,
+                              hipStream_t s);
 hipError_t launch_stem(int dtype, const StemArgs &a, hipStream_t s);
 hipError_t launch_fuse(int dtype, const FuseArgs &a, hipStream_t s);
 hipError_t launch_head(int dtype, const HeadArgs &a, hipStream_t s);
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t s);
 
 // rows per block of the conv kernels: buffers keep this many guard rows after the last image
-constexpr int kConvBlockRows = 256;
+constexpr int kConvBlockRows = 512;
 
 }  // namespace hrn

@@ -1,0 +1,33 @@
+"""Per-block phase timing of the grouped conv3x3 kernel (needs a build with -DHRN_C3_TIMING)."""
+import ctypes, importlib, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+lib_mod = importlib.import_module("simple-hrnet_amd._lib")
+lib_mod.HIPCC_FLAGS.append("-DHRN_C3_TIMING")
+lib_mod.LIB_PATH = lib_mod.LIB_PATH.replace(".so", "_timing.so")
+lib_mod.build(force=True)
+import torch
+pkg = importlib.import_module("simple-hrnet_amd")
+mb = int(os.environ.get("MB", "64"))
+net = pkg.NativeHRNet(48, 17, (384, 288), "bf16", max_batch=mb, device=0).load_state_dict(pkg.synth_state_dict(48, 17, 0))
+lib = lib_mod.load()
+lib.hrn_debug_c3_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+NB = 4096
+buf = np.zeros((NB, 8), np.int64)
+lib.hrn_debug_c3_timing(buf.ctypes.data, NB)          # allocate + arm
+x = torch.randn((mb, 3, 384, 288), device="cuda")
+for _ in range(3):
+    net(x)
+torch.cuda.synchronize()
+lib.hrn_debug_c3_timing(buf.ctypes.data, NB)
+b = buf[buf[:, 5] > 0]
+print("blocks of the last grouped launch:", len(b))
+for mr in (2, 4, 8):
+    for S in sorted(set(b[:, 7])):
+        sel = b[(b[:, 6] == mr) & (b[:, 7] == S)]
+        if not len(sel): continue
+        nh = sel[:, 5].mean()
+        print("MR=%d S=%d: %4d blocks, %.1f half-stages/block | per half-stage cycles: wait %.0f issue %.0f compute %.0f | epilogue/tile %.0f | total/block %.0f (ideal mfma %d/half)" % (
+            mr, S, len(sel), nh, (sel[:, 0] / sel[:, 5]).mean(), (sel[:, 1] / sel[:, 5]).mean(), (sel[:, 2] / sel[:, 5]).mean(),
+            (sel[:, 3] / np.maximum(1, sel[:, 5] / (2 * S))).mean(), sel[:, 4].mean(), 7 * 3 * mr * 16))
