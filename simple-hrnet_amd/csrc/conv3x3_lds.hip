@@ -34,6 +34,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+// The problem descriptors are read from memory, so their pointers are generic; tell the compiler they are
+// global, otherwise every access becomes a FLAT op, which counts on lgkmcnt as well and forces lgkmcnt(0)
+// drains in front of the MFMAs (measured: every wait in the chunk loop was a full drain).
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef const GLOBAL_AS unsigned short *gcu16;
+typedef GLOBAL_AS unsigned short *gu16;
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) {
@@ -42,9 +48,9 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     return (unsigned short)(u >> 16);
 }
 
-__device__ __forceinline__ void glds16(const void *gsrc, char *lds_wave_base) {
+__device__ __forceinline__ void glds16(const GLOBAL_AS void *gsrc, char *lds_wave_base) {
     // 64 lanes x 16 B -> LDS [lds_wave_base + lane*16); the base must be wave-uniform
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+    __builtin_amdgcn_global_load_lds(gsrc,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
@@ -76,9 +82,10 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
     if (ntile <= 0) return;
     const int S = p.slices;
     const int slab_units = (BM + 2 * p.wp + 2) * UPR;
-    const unsigned short *__restrict__ in = (const unsigned short *)p.in;
+    const gcu16 in = (gcu16)p.in;
     char *const wbuf = smem;
     char *const sbuf = smem + 2 * C3_WHALF;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;  // LDS byte address
 
     // per-lane LDS byte offset of k-group g of chunk c, relative to the lane's own pixel row in the slab
     int xoff[C3_NCH];
@@ -104,19 +111,23 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
     const int ch0 = nt * 16 * NRB + g * 4 * NRB;
     float bias[4 * NRB];
 #pragma unroll
-    for (int c = 0; c < 4 * NRB; ++c) bias[c] = p.bias[ch0 + c];
-    unsigned short *__restrict__ out = (unsigned short *)p.out;
-    const unsigned short *__restrict__ res = (const unsigned short *)p.res;
-    const char *const wsrc_nt = (const char *)p.w + (size_t)nt * S * (2 * C3_WHALF);
+    for (int c = 0; c < 4 * NRB; ++c) bias[c] = ((const GLOBAL_AS float *)p.bias)[ch0 + c];
+    const gu16 out = (gu16)p.out;
+    const gcu16 res = (gcu16)p.res;
+    const bool has_res = p.res != nullptr;
+    const GLOBAL_AS char *const wsrc_nt = (const GLOBAL_AS char *)p.w + (size_t)nt * S * (2 * C3_WHALF);
 
     // The LDS-DMA of half-stage (tt, s, hf) is cut into per-wave "pieces" (one 1 KiB instruction each):
     // pieces 0..2 = this wave's share of the weight half -> wbuf[hf]; pieces 3..9 = its share of the slab of
     // (tile tt, slice s) -> sbuf[par] (only when hf == 0).  A piece costs its wave ~150 issue cycles, so they
     // are spread over the chunk loop of the half-stage that runs meanwhile (the SIMD partner's MFMAs cover it).
+#ifdef HRN_C3_NODMA
+    const bool tt_guard = nb > 0;
+#endif
     struct Next {
-        const char *wsrc;   // nullptr: weights stay resident
+        const GLOBAL_AS char *wsrc;   // nullptr: weights stay resident
         char *wdst;
-        const char *ssrc;   // nullptr: no slab in this half-stage
+        const GLOBAL_AS char *ssrc;   // nullptr: no slab in this half-stage
         char *sdst;
     };
     auto plan = [&](int tt, int s, int hf, int par) {
@@ -127,11 +138,14 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
         n.sdst = sbuf + par * C3_SLAB + wave * 1024;
         if (hf == 0) {
             const long row0 = (long)(mt0 + tt) * BM - p.wp - 1;  // guard rows make negative / overrun rows valid
-            n.ssrc = (const char *)(in + row0 * p.cin + s * KS);
+            n.ssrc = (const GLOBAL_AS char *)(in + row0 * p.cin + s * KS);
         }
         return n;
     };
     auto piece = [&](const Next &n, int idx) {
+#ifdef HRN_C3_NODMA  // ablation build (tools/c3_timing.py): results are garbage, only the timing is of interest
+        if (tt_guard) return;
+#endif
         if (idx < 3) {
             const int u0 = idx * NT + wave * 64;
             if (n.wsrc && u0 < C3_WHALF / 16) glds16(n.wsrc + (size_t)(u0 + lane) * 16, n.wdst + u0 * 16);
@@ -157,9 +171,9 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
     }
     for (int tt = 0; tt < ntile; ++tt) {
 #pragma unroll
-        for (int i = 0; i < MR; ++i)
+        for (int i = 0; i < MR; ++i)  // accumulators start at the folded-BN bias
 #pragma unroll
-            for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{bias[j * 4], bias[j * 4 + 1], bias[j * 4 + 2], bias[j * 4 + 3]};
         for (int s = 0; s < S; ++s) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
@@ -180,39 +194,60 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                 // ---- last half-stage of the tile: request the residual tile now, it lands under the MFMAs
                 if (hf == 1 && s == S - 1) {
                     const int p0r = (mt0 + tt) * BM + wave * 16 * MR + li;
+                    if (has_res) {
 #pragma unroll
-                    for (int i = 0; i < MR; ++i) {
-                        int q = p0r + i * 16;
-                        if (q >= m) q = 0;
-                        const size_t o = (size_t)q * p.cout + ch0;
+                        for (int i = 0; i < MR; ++i) {
+                            int q = p0r + i * 16;
+                            if (q >= m) q = 0;
+                            const size_t o = (size_t)q * p.cout + ch0;
 #pragma unroll
-                        for (int j = 0; j < NRB; ++j) rpre[i][j] = res ? *(const s16x4 *)(res + o + j * 4) : s16x4{};
+                            for (int j = 0; j < NRB; ++j) rpre[i][j] = *(const GLOBAL_AS s16x4 *)(res + o + j * 4);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < MR; ++i)
+#pragma unroll
+                            for (int j = 0; j < NRB; ++j) rpre[i][j] = s16x4{};
                     }
                 }
                 C3_T(tC);
                 // ---- compute 7 chunks of K = 32 from wbuf[hf] and the current slab
-                const char *wl = wbuf + hf * C3_WHALF + lane * 16;
-                const char *sl = sbuf + slab_par * C3_SLAB + xrow0;
-                // explicit register double-buffering: the fragments of chunk c+1 are requested before the
-                // MFMAs of chunk c issue (one wave per SIMD: nothing else hides the LDS latency)
+                // Fragment reads are issued by hand (inline asm) one chunk ahead, with COUNTED waits: hipcc would
+                // drain lgkmcnt(0) in front of every other MFMA block here, stalling on reads it has just issued.
+                // Order is pinned with sched_barrier(0) (an MFMA must not be hoisted above the wait that covers
+                // its operands; cdna_hip_programming.md rule 18).
                 s16x8 wf[2][NRB], xf[2][MR];
-#pragma unroll
-                for (int j = 0; j < NRB; ++j) wf[0][j] = *(const s16x8 *)(wl + j * 1024);
-#pragma unroll
-                for (int i = 0; i < MR; ++i) xf[0][i] = *(const s16x8 *)(sl + i * 16 * ROWB + xoff[hf * C3_HCH]);
+                const unsigned wl_a = lds0 + hf * C3_WHALF + lane * 16;
+                const unsigned sl_a = lds0 + 2 * C3_WHALF + slab_par * C3_SLAB + xrow0;
+#define C3_READ_CHUNK(SET, C)                                                                                  \
+    {                                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < NRB; ++j)                                                        \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[SET][j]) : "v"(wl_a), "i"(((C)*NRB + j) * 1024)); \
+        const unsigned xa = sl_a + xoff[hf * C3_HCH + (C)];                                                    \
+        _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                         \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[SET][i]) : "v"(xa), "i"(i * 16 * ROWB));    \
+    }
+                C3_READ_CHUNK(0, 0)
 #pragma unroll
                 for (int c = 0; c < C3_HCH; ++c) {
                     const int cur = c & 1, nxt = cur ^ 1;
                     if (c + 1 < C3_HCH) {
-#pragma unroll
-                        for (int j = 0; j < NRB; ++j) wf[nxt][j] = *(const s16x8 *)(wl + ((c + 1) * NRB + j) * 1024);
-#pragma unroll
-                        for (int i = 0; i < MR; ++i)
-                            xf[nxt][i] = *(const s16x8 *)(sl + i * 16 * ROWB + xoff[hf * C3_HCH + c + 1]);
+                        C3_READ_CHUNK(nxt, c + 1)
                     }
-                    piece(nx, c);
-                    if (c + C3_HCH < NPIECE) piece(nx, c + C3_HCH);
-                    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this chunk's MFMAs
+                    // the two waves of a SIMD (w, w+4) issue their LDS-DMA pieces in different chunks
+                    {
+                        const int c0 = wave < 4 ? c : c - 3;   // waves 0-3: chunks 0..3, waves 4-7: chunks 3..6
+                        if (c0 >= 0 && c0 < 4) {
+                            if (3 * c0 < NPIECE) piece(nx, 3 * c0);
+                            if (3 * c0 + 1 < NPIECE) piece(nx, 3 * c0 + 1);
+                            if (3 * c0 + 2 < NPIECE) piece(nx, 3 * c0 + 2);
+                        }
+                    }
+                    if (c + 1 < C3_HCH)
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(NRB + MR) : "memory");  // chunk c landed, c+1 in flight
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -222,6 +257,7 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                                 acc[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#undef C3_READ_CHUNK
 #ifdef HRN_C3_TIMING
                 C3_T(tD);
                 t_wait += tB - tA, t_issue += tC - tB, t_comp += tD - tC, ++n_half;
@@ -244,16 +280,19 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
             const size_t o = (size_t)q * p.cout + ch0;
 #pragma unroll
             for (int j = 0; j < NRB; ++j) {
-                const s16x4 r4 = rpre[i][j];
-                s16x4 o4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bias[j * 4 + r] + bf2f((unsigned short)r4[r]);
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (!ok) v = 0.f;
-                    o4[r] = (short)f2bf(v);
-                }
-                *(s16x4 *)(out + o + j * 4) = o4;
+                // residual: two bf16 per dword -> fp32 with one shift / one mask each
+                const unsigned r01 = ((const unsigned *)&rpre[i][j])[0], r23 = ((const unsigned *)&rpre[i][j])[1];
+                float v0 = acc[i][j][0] + __uint_as_float(r01 << 16);
+                float v1 = acc[i][j][1] + __uint_as_float(r01 & 0xffff0000u);
+                float v2 = acc[i][j][2] + __uint_as_float(r23 << 16);
+                float v3 = acc[i][j][3] + __uint_as_float(r23 & 0xffff0000u);
+                if (p.relu) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f), v2 = fmaxf(v2, 0.f), v3 = fmaxf(v3, 0.f);
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                const bf16x2 lo = {(__bf16)v0, (__bf16)v1}, hi = {(__bf16)v2, (__bf16)v3};  // RNE, v_cvt_pk_bf16_f32
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                u32x2 pk = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+                if (!ok) pk = u32x2{0u, 0u};
+                *(GLOBAL_AS u32x2 *)(out + o + j * 4) = pk;
             }
         }
 #ifdef HRN_C3_TIMING
@@ -262,9 +301,9 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
 #endif
     }
 #ifdef HRN_C3_TIMING
-    if (tid == 0 && g_c3_timing) {
+    if (lane == 0 && g_c3_timing) {
         C3_T(t_end);
-        long long *o = g_c3_timing + (size_t)blockIdx.x * 8;
+        long long *o = g_c3_timing + ((size_t)blockIdx.x * 8 + wave) * 8;
         o[0] = t_wait, o[1] = t_issue, o[2] = t_comp, o[3] = t_epi, o[4] = t_end - t_begin, o[5] = n_half, o[6] = MR,
         o[7] = S;
     }
@@ -287,13 +326,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem 
 extern "C" int hrn_debug_c3_timing(long long *host_out, int max_blocks) {
     static long long *buf = nullptr;
     if (!buf) {
-        if (hipMalloc((void **)&buf, (size_t)max_blocks * 64) != hipSuccess) return -1;
-        (void)hipMemset(buf, 0, (size_t)max_blocks * 64);
+        if (hipMalloc((void **)&buf, (size_t)max_blocks * 512) != hipSuccess) return -1;
+        (void)hipMemset(buf, 0, (size_t)max_blocks * 512);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_c3_timing), &buf, sizeof(buf));
         return 0;
     }
     (void)hipDeviceSynchronize();
-    (void)hipMemcpy(host_out, buf, (size_t)max_blocks * 64, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(host_out, buf, (size_t)max_blocks * 512, hipMemcpyDeviceToHost);
     return 1;
 }
 #endif

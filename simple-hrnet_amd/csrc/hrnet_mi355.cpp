@@ -115,7 +115,8 @@ struct hrn_ctx {
 
     bool disable_lds = getenv("HRN_DISABLE_LDS") != nullptr;
     bool disable_group = getenv("HRN_DISABLE_GROUP") != nullptr;
-    int half_stages_per_block = getenv("HRN_HALF_STAGES") ? atoi(getenv("HRN_HALF_STAGES")) : 16;
+    int half_stages_per_block = getenv("HRN_HALF_STAGES") ? atoi(getenv("HRN_HALF_STAGES")) : 8;
+    int block_order = getenv("HRN_BLOCK_ORDER") ? atoi(getenv("HRN_BLOCK_ORDER")) : 1;
     int head_slabs = 1, head_slab_px = 1024;
     float *part_val = nullptr;
     int *part_idx = nullptr;
@@ -381,7 +382,13 @@ struct hrn_ctx {
             const int total = mgroups * cv.ntiles;
             for (int i = 0; i < total; ++i) {
                 const int mg = i / cv.ntiles, nt = i % cv.ntiles;
-                ents.push_back({(i + 0.5) / total, int2{(int)k | (nt << 8), mg * tpb}});
+                double key = (i + 0.5) / total;  // default: proportional interleave of the problems
+                if (block_order == 1) {          // longest-processing-time first (estimated block cost)
+                    int tiles = mtiles - mg * tpb;
+                    if (tiles > tpb) tiles = tpb;
+                    key = -(double)tiles * (cv.slices * 2.0 * (bm == 512 ? 4800.0 : 3700.0) + (bm == 512 ? 4500.0 : 2000.0)) + 1e-3 * key;
+                }
+                ents.push_back({key, int2{(int)k | (nt << 8), mg * tpb}});
             }
         }
         std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });

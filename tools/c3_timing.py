@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib_mod = importlib.import_module("simple-hrnet_amd._lib")
 lib_mod.HIPCC_FLAGS.append("-DHRN_C3_TIMING")
+for extra in os.environ.get("C3_DEFS", "").split():
+    lib_mod.HIPCC_FLAGS.append("-D" + extra)
 lib_mod.LIB_PATH = lib_mod.LIB_PATH.replace(".so", "_timing.so")
 lib_mod.build(force=True)
 import torch
@@ -14,20 +16,21 @@ net = pkg.NativeHRNet(48, 17, (384, 288), "bf16", max_batch=mb, device=0).load_s
 lib = lib_mod.load()
 lib.hrn_debug_c3_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 NB = 4096
-buf = np.zeros((NB, 8), np.int64)
+buf = np.zeros((NB, 8, 8), np.int64)
 lib.hrn_debug_c3_timing(buf.ctypes.data, NB)          # allocate + arm
 x = torch.randn((mb, 3, 384, 288), device="cuda")
 for _ in range(3):
     net(x)
 torch.cuda.synchronize()
 lib.hrn_debug_c3_timing(buf.ctypes.data, NB)
-b = buf[buf[:, 5] > 0]
+b = buf[buf[:, 0, 5] > 0]
 print("blocks of the last grouped launch:", len(b))
 for mr in (2, 4, 8):
-    for S in sorted(set(b[:, 7])):
-        sel = b[(b[:, 6] == mr) & (b[:, 7] == S)]
+    for S in sorted(set(b[:, 0, 7])):
+        sel = b[(b[:, 0, 6] == mr) & (b[:, 0, 7] == S)]
         if not len(sel): continue
-        nh = sel[:, 5].mean()
-        print("MR=%d S=%d: %4d blocks, %.1f half-stages/block | per half-stage cycles: wait %.0f issue %.0f compute %.0f | epilogue/tile %.0f | total/block %.0f (ideal mfma %d/half)" % (
-            mr, S, len(sel), nh, (sel[:, 0] / sel[:, 5]).mean(), (sel[:, 1] / sel[:, 5]).mean(), (sel[:, 2] / sel[:, 5]).mean(),
-            (sel[:, 3] / np.maximum(1, sel[:, 5] / (2 * S))).mean(), sel[:, 4].mean(), 7 * 3 * mr * 16))
+        nh = sel[:, 0, 5].mean()
+        print("MR=%d S=%d: %4d blocks, %.1f half-stages/block, total/block %.0f, epilogue/tile %.0f (ideal mfma %d/half/wave)" % (
+            mr, S, len(sel), nh, sel[:, 0, 4].mean(), (sel[:, 0, 3] / np.maximum(1, sel[:, 0, 5] / (2 * S))).mean(), 7 * 3 * mr * 16))
+        for w in range(8):
+            print("    wave %d: wait %.0f issue %.0f compute %.0f" % (w, (sel[:, w, 0] / sel[:, w, 5]).mean(), (sel[:, w, 1] / sel[:, w, 5]).mean(), (sel[:, w, 2] / sel[:, w, 5]).mean()))
