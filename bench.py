@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=288)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--max-batch", type=int, default=int(os.environ.get("HRN_MAX_BATCH", "64")),
+    ap.add_argument("--max-batch", type=int, default=int(os.environ.get("HRN_MAX_BATCH", "256")),
                     help="crops per internal pass (workspace size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")

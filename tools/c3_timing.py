@@ -15,7 +15,7 @@ mb = int(os.environ.get("MB", "64"))
 net = pkg.NativeHRNet(48, 17, (384, 288), "bf16", max_batch=mb, device=0).load_state_dict(pkg.synth_state_dict(48, 17, 0))
 lib = lib_mod.load()
 lib.hrn_debug_c3_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
-NB = 4096
+NB = 32768
 buf = np.zeros((NB, 8, 8), np.int64)
 lib.hrn_debug_c3_timing(buf.ctypes.data, NB)          # allocate + arm
 x = torch.randn((mb, 3, 384, 288), device="cuda")
