@@ -124,6 +124,7 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
 #ifdef HRN_C3_NODMA
     const bool tt_guard = nb > 0;
 #endif
+    int npost = 0;  // LDS-DMA instructions this wave has issued since it requested the residual tile (wave-uniform)
     struct Next {
         const GLOBAL_AS char *wsrc;   // nullptr: weights stay resident
         char *wdst;
@@ -148,16 +149,24 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
 #endif
         if (idx < 3) {
             const int u0 = idx * NT + wave * 64;
-            if (n.wsrc && u0 < C3_WHALF / 16) glds16(n.wsrc + (size_t)(u0 + lane) * 16, n.wdst + u0 * 16);
+            if (n.wsrc && u0 < C3_WHALF / 16) {
+                glds16(n.wsrc + (size_t)(u0 + lane) * 16, n.wdst + u0 * 16);
+                ++npost;
+            }
         } else {
             const int k = idx - 3;
-            if (n.ssrc && k * NT + wave * 64 < slab_units) glds16(n.ssrc + srel[k], n.sdst + k * NT * 16);
+            if (n.ssrc && k * NT + wave * 64 < slab_units) {
+                glds16(n.ssrc + srel[k], n.sdst + k * NT * 16);
+                ++npost;
+            }
         }
     };
     constexpr int NPIECE = 3 + SLAB_ITERS;
 
     f32x4 acc[MR][NRB];
-    s16x4 rpre[MR][NRB];
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    u32x2 rpre[MR][NRB];
+    bool after_epilogue = false;
     int slab_par = 0;
 #ifdef HRN_C3_TIMING
     long long t_wait = 0, t_issue = 0, t_comp = 0, t_epi = 0;
@@ -178,8 +187,14 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 C3_T(tA);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed
-                __syncthreads();  // everyone's has; everyone is done reading the buffers refilled below
+                // this wave's LDS-DMA for this half-stage has landed.  vmcnt retires in order and counts stores:
+                // right after an epilogue the youngest MR*NRB operations are its stores, which may stay in flight
+                if (after_epilogue)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MR * NRB) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                after_epilogue = false;
+                __builtin_amdgcn_s_barrier();  // everyone's has; everyone is done reading the buffers refilled below
                 C3_T(tB);
                 // ---- what the next half-stage needs (issued piecewise inside the chunk loop below)
                 Next nx;
@@ -199,16 +214,18 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                         for (int i = 0; i < MR; ++i) {
                             int q = p0r + i * 16;
                             if (q >= m) q = 0;
-                            const size_t o = (size_t)q * p.cout + ch0;
+                            const gcu16 rp = res + (size_t)q * p.cout + ch0;
 #pragma unroll
-                            for (int j = 0; j < NRB; ++j) rpre[i][j] = *(const GLOBAL_AS s16x4 *)(res + o + j * 4);
+                            for (int j = 0; j < NRB; ++j)  // hand-issued: waited for with a COUNTED vmcnt in the epilogue
+                                asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(rpre[i][j]) : "v"(rp), "i"(j * 8));
                         }
                     } else {
 #pragma unroll
                         for (int i = 0; i < MR; ++i)
 #pragma unroll
-                            for (int j = 0; j < NRB; ++j) rpre[i][j] = s16x4{};
+                            for (int j = 0; j < NRB; ++j) rpre[i][j] = u32x2{0u, 0u};
                     }
+                    npost = 0;
                 }
                 C3_T(tC);
                 // ---- compute 7 chunks of K = 32 from wbuf[hf] and the current slab
@@ -267,21 +284,37 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
         }
         // ---- epilogue: + bias (+ residual) (ReLU), zero on pad pixels; lane owns 12 contiguous channels
         C3_T(tE);
+        // the residual loads are older than the `npost` LDS-DMA instructions issued after them: wait for exactly those
+        if (has_res) {
+            switch (npost) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         const int p0 = (mt0 + tt) * BM;
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
-            const int q = p0 + wave * 16 * MR + i * 16 + li;
-            if (q >= m) continue;
+            const int q = p0 + wave * 16 * MR + i * 16 + li;  // q >= m lands in the zero tail guard: store zeros
             const int n_img = (int)(((unsigned long long)(unsigned)q * p.magic_hpwp) >> p.shift_hpwp);
             const int rem = q - n_img * p.hpwp;
             const int ho = (int)(((unsigned long long)(unsigned)rem * p.magic_wp) >> p.shift_wp);
             const int wo = rem - ho * p.wp;
-            const bool ok = (ho < p.h) && (wo < p.wd);
+            const bool ok = (q < m) && (ho < p.h) && (wo < p.wd);
             const size_t o = (size_t)q * p.cout + ch0;
 #pragma unroll
             for (int j = 0; j < NRB; ++j) {
                 // residual: two bf16 per dword -> fp32 with one shift / one mask each
-                const unsigned r01 = ((const unsigned *)&rpre[i][j])[0], r23 = ((const unsigned *)&rpre[i][j])[1];
+                const unsigned r01 = rpre[i][j][0], r23 = rpre[i][j][1];
                 float v0 = acc[i][j][0] + __uint_as_float(r01 << 16);
                 float v1 = acc[i][j][1] + __uint_as_float(r01 & 0xffff0000u);
                 float v2 = acc[i][j][2] + __uint_as_float(r23 << 16);
@@ -289,12 +322,12 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                 if (p.relu) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f), v2 = fmaxf(v2, 0.f), v3 = fmaxf(v3, 0.f);
                 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
                 const bf16x2 lo = {(__bf16)v0, (__bf16)v1}, hi = {(__bf16)v2, (__bf16)v3};  // RNE, v_cvt_pk_bf16_f32
-                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
                 u32x2 pk = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
                 if (!ok) pk = u32x2{0u, 0u};
                 *(GLOBAL_AS u32x2 *)(out + o + j * 4) = pk;
             }
         }
+        after_epilogue = true;
 #ifdef HRN_C3_TIMING
         C3_T(tF);
         t_epi += tF - tE;
