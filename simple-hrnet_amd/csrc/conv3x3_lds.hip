@@ -124,24 +124,29 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
 #ifdef HRN_C3_NODMA
     const bool tt_guard = nb > 0;
 #endif
-    int npost = 0;  // LDS-DMA instructions this wave has issued since it requested the residual tile (wave-uniform)
+    // piece counts of THIS wave (wave-uniform; plain scalars -- a counter bumped inside the lambdas ends up in
+    // scratch memory, and every scratch access is a VMEM op that drains the LDS-DMA queue with vmcnt(0))
+    const int nw_wave = wave < 5 ? 3 : 2;                       // 1344 weight units / (512 per piece row)
+    int ns_wave = (slab_units - wave * 64 + NT - 1) / NT;       // slab pieces: k*512 + wave*64 < slab_units
+    ns_wave = ns_wave < 0 ? 0 : (ns_wave > SLAB_ITERS ? SLAB_ITERS : ns_wave);
+    int npost = 0;  // LDS-DMA instructions issued after the residual request (last half-stage of a tile)
+    int nslab = 0;  // slab pieces issued during the hf == 0 half-stage (they may stay in flight one more)
     struct Next {
         const GLOBAL_AS char *wsrc;   // nullptr: weights stay resident
         char *wdst;
         const GLOBAL_AS char *ssrc;   // nullptr: no slab in this half-stage
         char *sdst;
     };
-    auto plan = [&](int tt, int s, int hf, int par) {
-        Next n;
+    // weights of half-stage (tt, s, hf) -> wbuf[hf]   (single-slice problems keep both halves resident)
+    auto plan_w = [&](Next &n, int tt, int s, int hf) {
         n.wsrc = (S > 1 || tt == 0) ? wsrc_nt + (size_t)(2 * s + hf) * C3_WHALF : nullptr;
         n.wdst = wbuf + hf * C3_WHALF;
-        n.ssrc = nullptr;
+    };
+    // slab of (tile tt, slice s) -> sbuf[par]
+    auto plan_s = [&](Next &n, int tt, int s, int par) {
+        const long row0 = (long)(mt0 + tt) * BM - p.wp - 1;  // guard rows make negative / overrun rows valid
+        n.ssrc = (const GLOBAL_AS char *)(in + row0 * p.cin + s * KS);
         n.sdst = sbuf + par * C3_SLAB + wave * 1024;
-        if (hf == 0) {
-            const long row0 = (long)(mt0 + tt) * BM - p.wp - 1;  // guard rows make negative / overrun rows valid
-            n.ssrc = (const GLOBAL_AS char *)(in + row0 * p.cin + s * KS);
-        }
-        return n;
     };
     auto piece = [&](const Next &n, int idx) {
 #ifdef HRN_C3_NODMA  // ablation build (tools/c3_timing.py): results are garbage, only the timing is of interest
@@ -151,13 +156,11 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
             const int u0 = idx * NT + wave * 64;
             if (n.wsrc && u0 < C3_WHALF / 16) {
                 glds16(n.wsrc + (size_t)(u0 + lane) * 16, n.wdst + u0 * 16);
-                ++npost;
             }
         } else {
             const int k = idx - 3;
             if (n.ssrc && k * NT + wave * 64 < slab_units) {
                 glds16(n.ssrc + srel[k], n.sdst + k * NT * 16);
-                ++npost;
             }
         }
     };
@@ -174,7 +177,9 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
     C3_T(t_begin);
 #endif
     {
-        const Next n0 = plan(0, 0, 0, 0);
+        Next n0;
+        plan_w(n0, 0, 0, 0);
+        plan_s(n0, 0, 0, 0);
 #pragma unroll
         for (int k = 0; k < NPIECE; ++k) piece(n0, k);
     }
@@ -189,22 +194,43 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                 C3_T(tA);
                 // this wave's LDS-DMA for this half-stage has landed.  vmcnt retires in order and counts stores:
                 // right after an epilogue the youngest MR*NRB operations are its stores, which may stay in flight
-                if (after_epilogue)
+                if (hf == 1) {
+                    // the youngest `nslab` operations are the NEXT slice's slab pieces (issued during hf == 0,
+                    // after this half-stage's weights): they get a second half-stage to land
+                    switch (nslab) {
+                        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                        default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                    }
+                } else if (after_epilogue) {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MR * NRB) : "memory");
-                else
+                } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 after_epilogue = false;
                 __builtin_amdgcn_s_barrier();  // everyone's has; everyone is done reading the buffers refilled below
                 C3_T(tB);
-                // ---- what the next half-stage needs (issued piecewise inside the chunk loop below)
+                // ---- what to prefetch while this half-stage computes (issued piecewise inside the chunk loop):
+                //      hf == 0: the weights of (s, hf 1) and already the slab of the NEXT slice / tile;
+                //      hf == 1: the weights of the next slice's first half.
                 Next nx;
-                if (hf == 0) {
-                    nx = plan(tt, s, 1, slab_par);  // weights only
-                } else {
+                nx.wsrc = nullptr, nx.ssrc = nullptr, nx.wdst = wbuf, nx.sdst = sbuf;
+                {
                     int s2 = s + 1, t2 = tt;
                     if (s2 == S) s2 = 0, ++t2;
-                    nx = plan(t2, s2, 0, slab_par ^ 1);
-                    if (t2 >= ntile) nx.wsrc = nullptr, nx.ssrc = nullptr;
+                    if (hf == 0) {
+                        plan_w(nx, tt, s, 1);
+                        if (t2 < ntile) plan_s(nx, t2, s2, slab_par ^ 1);
+                        nslab = nx.ssrc ? ns_wave : 0;
+                    } else {
+                        if (t2 < ntile) plan_w(nx, t2, s2, 0);
+                        npost = nx.wsrc ? nw_wave : 0;
+                    }
                 }
                 // ---- last half-stage of the tile: request the residual tile now, it lands under the MFMAs
                 if (hf == 1 && s == S - 1) {
@@ -225,7 +251,6 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
 #pragma unroll
                             for (int j = 0; j < NRB; ++j) rpre[i][j] = u32x2{0u, 0u};
                     }
-                    npost = 0;
                 }
                 C3_T(tC);
                 // ---- compute 7 chunks of K = 32 from wbuf[hf] and the current slab
