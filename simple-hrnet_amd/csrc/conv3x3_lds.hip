@@ -23,7 +23,7 @@
 //   * an LDS-DMA instruction costs its wave ~100+ issue cycles and the epilogue is store-latency bound, so
 //     two waves share each SIMD: while one issues loads / stores, the other keeps the MFMA pipe busy.
 //     The residual tile is requested before the last half-stage's MFMAs and is in registers by the epilogue.
-// Tile: wave = 16*MR pixels x 48 couts (MR = 4: BM = 512, MR = 2: BM = 256 for the 96x72 branch whose halo
+// Tile: wave = 16*MR pixels x 48 couts (MR = 4: BM = 512, MR = 3: BM = 384 for the 96x72 branch whose halo
 // would not fit twice); operands swapped (D = W * X^T) so a lane owns 12 contiguous channels of one pixel.
 // One launch covers a GROUP of independent convolutions (the k-th conv of every branch of a stage module).
 #include "kernels.h"
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem 
     if (p.bm == 512)
         conv3_run<4>(p, bm.x >> 8, bm.y, nb, smem);
     else
-        conv3_run<2>(p, bm.x >> 8, bm.y, nb, smem);
+        conv3_run<3>(p, bm.x >> 8, bm.y, nb, smem);  // bm == 384
 }
 
 #ifdef HRN_C3_TIMING
@@ -395,7 +395,7 @@ extern "C" int hrn_debug_c3_timing(long long *host_out, int max_blocks) {
 }
 #endif
 
-int conv3x3_lds_bm(int wp) { return (512 + 2 * wp + 2) * 96 <= C3_SLAB ? 512 : 256; }
+int conv3x3_lds_bm(int wp) { return (512 + 2 * wp + 2) * 96 <= C3_SLAB ? 512 : 384; }
 
 hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb,
                               hipStream_t s) {

@@ -386,7 +386,7 @@ struct hrn_ctx {
                 if (block_order == 1) {          // longest-processing-time first (estimated block cost)
                     int tiles = mtiles - mg * tpb;
                     if (tiles > tpb) tiles = tpb;
-                    key = -(double)tiles * (cv.slices * 2.0 * (bm == 512 ? 4800.0 : 3700.0) + (bm == 512 ? 4500.0 : 2000.0)) + 1e-3 * key;
+                    key = -(double)tiles * (cv.slices * 2.0 * (bm == 512 ? 4300.0 : 3500.0) + (bm == 512 ? 5000.0 : 3000.0)) + 1e-3 * key;
                 }
                 ents.push_back({key, int2{(int)k | (nt << 8), mg * tpb}});
             }
