@@ -73,8 +73,11 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
     using elem = typename T::elem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const int m0 = (blockIdx.x * 4 + wave) * (16 * MR);
-    const int ng = blockIdx.y;
+    // 1-D grid, cout tile fastest: the blocks that share an activation tile are dispatched together, so the
+    // tile is fetched from HBM once and re-read from L2
+    const int ngroups = p.cout / (16 * NR);
+    const int ng = blockIdx.x % ngroups;
+    const int m0 = ((blockIdx.x / ngroups) * 4 + wave) * (16 * MR);
     const elem *__restrict__ in = (const elem *)p.in;
 
     long inrow[MR];
@@ -152,20 +155,39 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
         const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
         const bool ok = (ho < p.out_h) && (wo < p.out_w);
         const size_t o = (size_t)q * p.cout + ch0;
+        if constexpr (DT == DT_BF16 && (NR % 2 == 0)) {
+            // 8 contiguous channels per access: 16-byte residual loads and stores
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            typename T::out4 r4 = {};
-            if (res) r4 = *(const typename T::out4 *)(res + o + j * 4);
-            typename T::out4 o4;
+            for (int j = 0; j < NR; j += 2) {
+                s16x8 r8 = {};
+                if (res) r8 = *(const s16x8 *)(res + o + j * 4);
+                s16x8 o8;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r] + bias[j * 4 + r];
-                if (res) v += T::ld((elem)r4[r]);
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (!ok) v = 0.f;
-                o4[r] = T::st(v);
+                for (int r = 0; r < 8; ++r) {
+                    float v = acc[i][j + (r >> 2)][r & 3] + bias[j * 4 + r];
+                    if (res) v += T::ld((elem)r8[r]);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (!ok) v = 0.f;
+                    o8[r] = (short)T::st(v);
+                }
+                *(s16x8 *)(out + o + j * 4) = o8;
             }
-            *(typename T::out4 *)(out + o + j * 4) = o4;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                typename T::out4 r4 = {};
+                if (res) r4 = *(const typename T::out4 *)(res + o + j * 4);
+                typename T::out4 o4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bias[j * 4 + r];
+                    if (res) v += T::ld((elem)r4[r]);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (!ok) v = 0.f;
+                    o4[r] = T::st(v);
+                }
+                *(typename T::out4 *)(out + o + j * 4) = o4;
+            }
         }
     }
 }
@@ -173,7 +195,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
 template <int DT, int NR>
 static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
     constexpr int MR = 4;
-    dim3 grid((a.m + 64 * MR - 1) / (64 * MR), a.cout / (16 * NR));
+    dim3 grid(((a.m + 64 * MR - 1) / (64 * MR)) * (a.cout / (16 * NR)));
     hipLaunchKernelGGL((conv_direct_kernel<DT, NR, MR>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -202,50 +224,55 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs p) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int m = p.n * p.out_hpwp;
     if (q >= m) return;
-    const int cg = blockIdx.y;
     const int n = q / p.out_hpwp, rem = q - n * p.out_hpwp;
     const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
-    float acc[16];
     const bool ok = ho < p.out_h && wo < p.out_w;
-    if (ok) {
+    // one thread = one output pixel x all 64 channels: the 27 inputs are fetched once, the 128-byte (bf16)
+    // NHWC row is written with full 16-byte stores; weights are wave-uniform -> scalar loads / SGPR operands
+    float x[27];
+    const float *img = p.images + (size_t)n * 3 * p.H * p.W;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = 2 * ho + kh - 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = 2 * wo + kw - 1;
+                float v = 0.f;
+                if (ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = img[((size_t)ci * p.H + iy) * p.W + ix];
+                x[ci * 9 + kh * 3 + kw] = v;
+            }
+        }
+    typename T::elem *o = (typename T::elem *)p.out + (size_t)q * 64;
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+        float acc[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc[c] = p.bias[cg * 16 + c];
-        const float *img = p.images + (size_t)n * 3 * p.H * p.W;
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci)
+        for (int k = 0; k < 27; ++k) {
+            const float *wk = p.w + k * 64 + cg * 16;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int iy = 2 * ho + kh - 1;
+            for (int c = 0; c < 16; ++c) acc[c] = fmaf(x[k], wk[c], acc[c]);
+        }
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ix = 2 * wo + kw - 1;
-                    float x = 0.f;
-                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) x = img[((size_t)ci * p.H + iy) * p.W + ix];
-                    const float *wk = p.w + (ci * 9 + kh * 3 + kw) * 64 + cg * 16;
+        for (int v = 0; v < 16 / T::VEC; ++v) {
+            typename T::vec ov;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) acc[c] = fmaf(x, wk[c], acc[c]);
-                }
+            for (int r = 0; r < T::VEC; ++r) {
+                const float f = ok ? fmaxf(acc[v * T::VEC + r], 0.f) : 0.f;
+                ov[r] = T::st(f);
             }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = fmaxf(acc[c], 0.f);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-    }
-    typename T::elem *o = (typename T::elem *)p.out + (size_t)q * 64 + cg * 16;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        typename T::out4 o4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o4[r] = T::st(acc[v * 4 + r]);
-        *(typename T::out4 *)(o + v * 4) = o4;
+            *(typename T::vec *)(o + cg * 16 + v * T::VEC) = ov;
+        }
     }
 }
 
 hipError_t launch_stem(int dtype, const StemArgs &a, hipStream_t s) {
     const int m = a.n * a.out_hpwp;
     if (m <= 0) return hipSuccess;
-    dim3 grid((m + 255) / 256, 4);
+    dim3 grid((m + 255) / 256);
     if (dtype == DT_BF16)
         hipLaunchKernelGGL(stem_kernel<DT_BF16>, grid, dim3(256), 0, s, a);
     else
