@@ -155,3 +155,50 @@ def test_full_size_properties_bf16(pkg):
     T = _oracle()
     np.testing.assert_array_equal(T.decode_heatmaps(hm1.cpu().numpy(), boxes), p1.cpu().numpy())
     b.close()
+
+
+def test_weight_blob_broadcast_path_single_gpu(pkg):
+    """The multi-GPU weight distribution minus RCCL: the packed blob of a loaded engine is exposed as a
+    zero-copy uint8 CUDA tensor, copied into a second (unloaded) engine's blob and adopted -- what
+    ShardedHRNet.load_and_broadcast does with dist.broadcast -- and both engines then agree bit for bit."""
+    c, h, w, n = 32, 64, 64, 3
+    src = _engine(pkg, c, h, w, "bf16", 4)
+    dst = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=4, device=0)
+    a, b = src.weight_blob_tensor(), dst.weight_blob_tensor()
+    assert a.dtype == torch.uint8 and a.is_cuda and a.numel() == src.weight_blob_bytes() == b.numel()
+    assert a.data_ptr() != b.data_ptr()
+    b.copy_(a)
+    torch.cuda.synchronize()
+    dst.adopt_weights()
+    crops = torch.from_numpy(pkg.synth_crops(n, h, w, seed=4)).cuda()
+    boxes = pkg.synth_boxes(n, seed=4)
+    p1, p2 = src.predict_crops(crops, boxes), dst.predict_crops(crops, boxes)
+    assert torch.equal(p1, p2)
+    # and through the sharding front-end with a single process (world size 1)
+    sh = load_pkg("dist").ShardedHRNet(dst, None)
+    assert torch.equal(sh.predict_crops_sharded(crops, boxes), p1)
+    assert torch.equal(sh.predict_crops_local_then_gather(crops, boxes), p1)
+    src.close()
+    dst.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_w32_config2_shape_batch64(pkg, dtype):
+    """BASELINE configs[1]: HRNet-W32 256x192, batch 64, one GPU.  The oracle at this size takes ~3 s on CPU,
+    so it is checked on the first 4 crops; the rest by batch-position invariance."""
+    T = _oracle()
+    c, h, w, n = 32, 256, 192, 64
+    crops_np = pkg.synth_crops(n, h, w, seed=8)
+    boxes = pkg.synth_boxes(n, seed=8)
+    net = _engine(pkg, c, h, w, dtype, max_batch=64)
+    hm, pts = net.predict_crops(torch.from_numpy(crops_np).cuda(), boxes, return_heatmaps=True)
+    sd = pkg.synth.to_torch_state_dict(state_dict_np(c))
+    ref_hm, ref_pts = T.predict_crops(sd, torch.from_numpy(crops_np[:4]), boxes[:4])
+    if dtype == "fp32":
+        np.testing.assert_allclose(hm[:4].cpu().numpy(), ref_hm, rtol=0, atol=HM_ATOL_F32)
+        np.testing.assert_array_equal(pts[:4].cpu().numpy()[..., :2], ref_pts[..., :2])
+    else:
+        assert np.abs(hm[:4].cpu().numpy() - ref_hm).max() < 0.05 * ref_hm.std() + 0.05
+    hm_b, pts_b = net.predict_crops(torch.from_numpy(crops_np[::-1].copy()).cuda(), boxes[::-1].copy(), return_heatmaps=True)
+    assert torch.equal(hm_b.flip(0), hm) and torch.equal(pts_b.flip(0), pts)
+    net.close()
