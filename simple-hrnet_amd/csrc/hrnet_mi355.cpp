@@ -120,6 +120,7 @@ struct hrn_ctx {
     bool disable_lds = getenv("HRN_DISABLE_LDS") != nullptr;
     bool disable_group = getenv("HRN_DISABLE_GROUP") != nullptr;
     bool disable_tap = getenv("HRN_DISABLE_TAP") != nullptr;
+    bool direct_nr6 = getenv("HRN_DIRECT_NR6") ? atoi(getenv("HRN_DIRECT_NR6")) != 0 : true;
     bool tap_stride2 = getenv("HRN_TAP_STRIDE2") != nullptr;  // stride-2 via the tap kernel (slower than direct so far)
     int half_stages_per_block = getenv("HRN_HALF_STAGES") ? atoi(getenv("HRN_HALF_STAGES")) : 8;
     int block_order = getenv("HRN_BLOCK_ORDER") ? atoi(getenv("HRN_BLOCK_ORDER")) : 1;
@@ -166,6 +167,7 @@ struct hrn_ctx {
         op.kchunks = (K + kc - 1) / kc;
         op.kpad = op.kchunks * kc;
         op.nr = (cout % 64 == 0) ? 4 : (cout % 48 == 0) ? 3 : 2;
+        if (dtype == HRN_BF16 && stride == 2 && cout % 96 == 0 && direct_nr6) op.nr = 6;  // halves the A gathers per MFMA
         op.flops = 2.0 * cout * (double)K * oh * ow;
         if (dtype == HRN_BF16 && k == 3 && stride == 1 && op.cin % 48 == 0 && cout % 48 == 0 && !disable_lds) {
             op.algo = 1, op.ks = 48, op.nr = 3;

@@ -203,6 +203,7 @@ static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
 hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s) {
     if (a.m <= 0) return hipSuccess;
     if (dtype == DT_BF16) {
+        if (nr == 6) return launch_conv_t<DT_BF16, 6>(a, s);
         if (nr == 4) return launch_conv_t<DT_BF16, 4>(a, s);
         if (nr == 3) return launch_conv_t<DT_BF16, 3>(a, s);
         if (nr == 2) return launch_conv_t<DT_BF16, 2>(a, s);
