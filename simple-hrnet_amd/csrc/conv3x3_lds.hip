@@ -168,7 +168,9 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
 
     f32x4 acc[MR][NRB];
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-    u32x2 rpre[MR][NRB];
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 rpre4[MR];   // residual channels 0..7 of the lane's 12
+    u32x2 rpre2[MR];   // residual channels 8..11
     bool after_epilogue = false;
     int slab_par = 0;
 #ifdef HRN_C3_TIMING
@@ -193,7 +195,7 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
             for (int hf = 0; hf < 2; ++hf) {
                 C3_T(tA);
                 // this wave's LDS-DMA for this half-stage has landed.  vmcnt retires in order and counts stores:
-                // right after an epilogue the youngest MR*NRB operations are its stores, which may stay in flight
+                // right after an epilogue the youngest 2*MR operations are its stores, which may stay in flight
                 if (hf == 1) {
                     // the youngest `nslab` operations are the NEXT slice's slab pieces (issued during hf == 0,
                     // after this half-stage's weights): they get a second half-stage to land
@@ -208,7 +210,7 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                         default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
                     }
                 } else if (after_epilogue) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MR * NRB) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MR * 2) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -241,15 +243,14 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                             int q = p0r + i * 16;
                             if (q >= m) q = 0;
                             const gcu16 rp = res + (size_t)q * p.cout + ch0;
-#pragma unroll
-                            for (int j = 0; j < NRB; ++j)  // hand-issued: waited for with a COUNTED vmcnt in the epilogue
-                                asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(rpre[i][j]) : "v"(rp), "i"(j * 8));
+                            // hand-issued (two instructions per fragment): waited for with a COUNTED vmcnt in the epilogue
+                            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rpre4[i]) : "v"(rp));
+                            asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=v"(rpre2[i]) : "v"(rp));
                         }
                     } else {
 #pragma unroll
                         for (int i = 0; i < MR; ++i)
-#pragma unroll
-                            for (int j = 0; j < NRB; ++j) rpre[i][j] = u32x2{0u, 0u};
+                            rpre4[i] = u32x4{0u, 0u, 0u, 0u}, rpre2[i] = u32x2{0u, 0u};
                     }
                 }
                 C3_T(tC);
@@ -336,10 +337,11 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
             const int wo = rem - ho * p.wp;
             const bool ok = (q < m) && (ho < p.h) && (wo < p.wd);
             const size_t o = (size_t)q * p.cout + ch0;
+            unsigned pk[2 * NRB];
 #pragma unroll
             for (int j = 0; j < NRB; ++j) {
                 // residual: two bf16 per dword -> fp32 with one shift / one mask each
-                const unsigned r01 = rpre[i][j][0], r23 = rpre[i][j][1];
+                const unsigned r01 = j < 2 ? rpre4[i][2 * j] : rpre2[i][0], r23 = j < 2 ? rpre4[i][2 * j + 1] : rpre2[i][1];
                 float v0 = acc[i][j][0] + __uint_as_float(r01 << 16);
                 float v1 = acc[i][j][1] + __uint_as_float(r01 & 0xffff0000u);
                 float v2 = acc[i][j][2] + __uint_as_float(r23 << 16);
@@ -347,10 +349,12 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                 if (p.relu) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f), v2 = fmaxf(v2, 0.f), v3 = fmaxf(v3, 0.f);
                 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
                 const bf16x2 lo = {(__bf16)v0, (__bf16)v1}, hi = {(__bf16)v2, (__bf16)v3};  // RNE, v_cvt_pk_bf16_f32
-                u32x2 pk = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
-                if (!ok) pk = u32x2{0u, 0u};
-                *(GLOBAL_AS u32x2 *)(out + o + j * 4) = pk;
+                pk[2 * j] = ok ? __builtin_bit_cast(unsigned, lo) : 0u;
+                pk[2 * j + 1] = ok ? __builtin_bit_cast(unsigned, hi) : 0u;
             }
+            // 24 contiguous bytes per lane: one 16-byte + one 8-byte store (store issue count is what the tail costs)
+            *(GLOBAL_AS u32x4 *)(out + o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            *(GLOBAL_AS u32x2 *)(out + o + 8) = u32x2{pk[4], pk[5]};
         }
         after_epilogue = true;
 #ifdef HRN_C3_TIMING
