@@ -458,16 +458,24 @@ struct hrn_ctx {
             const int tpb = conv3_tiles_per_block(cv);
             const int mgroups = (mtiles + tpb - 1) / tpb;
             const int total = mgroups * cv.ntiles;
-            for (int i = 0; i < total; ++i) {
-                const int mg = i / cv.ntiles, nt = i % cv.ntiles;
-                double key = (i + 0.5) / total;  // default: proportional interleave of the problems
-                if (block_order == 1) {          // longest-processing-time first (estimated block cost)
-                    int tiles = mtiles - mg * tpb;
-                    if (tiles > tpb) tiles = tpb;
-                    key = -(double)tiles * (cv.slices * 2.0 * (bm == 512 ? 4300.0 : 3500.0) + (bm == 512 ? 5000.0 : 3000.0)) + 1e-3 * key;
-                }
-                ents.push_back({key, int2{(int)k | (nt << 8), mg * tpb}});
-            }
+            // XCD-aware order inside a problem: the hardware places block id b on XCD b % 8 (private L2 each).  Emit
+            // rounds of 8 M groups x all cout tiles with the M group varying fastest, so the cout tiles of one M group
+            // are 8 ids apart = on the same XCD, and re-read its slab from that L2 instead of over the fabric.
+            int seq = 0;
+            for (int round = 0; round * 8 < mgroups; ++round)
+                for (int nt = 0; nt < cv.ntiles; ++nt)
+                    for (int x = 0; x < 8; ++x) {
+                        const int mg = round * 8 + x;
+                        if (mg >= mgroups) continue;
+                        const int i = seq++;
+                        double key = (i + 0.5) / total;  // proportional interleave of the problems
+                        if (block_order == 1) {          // longest-processing-time first (estimated block cost)
+                            int tiles = mtiles - mg * tpb;
+                            if (tiles > tpb) tiles = tpb;
+                            key = -(double)tiles * (cv.slices * 2.0 * (bm == 512 ? 4300.0 : 3500.0) + (bm == 512 ? 5000.0 : 3000.0)) + 1e-3 * key;
+                        }
+                        ents.push_back({key, int2{(int)k | (nt << 8), mg * tpb}});
+                    }
         }
         std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
         if (out) {
