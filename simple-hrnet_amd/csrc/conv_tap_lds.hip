@@ -48,8 +48,11 @@ __global__ __launch_bounds__(256, 2) void conv_tap_lds_kernel(const TapConvArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
-    const int nt = blockIdx.x % p.ntiles, mt = blockIdx.x / p.ntiles;
+    // XCD-aware ids (block b runs on XCD b % 8): the cout tiles of one M tile are 8 ids apart
+    const int nt = (blockIdx.x >> 3) % p.ntiles;
+    const int mt = (blockIdx.x / (8 * p.ntiles)) * 8 + (blockIdx.x & 7);
     const int p0 = mt * TAP_BM;
+    if (p0 >= p.m) return;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
     f32x4 acc[MR][NRB];
@@ -173,7 +176,7 @@ static hipError_t launch_tap_t(const TapConvArgs &a, hipStream_t s) {
         attr_set = true;
     }
     const int mtiles = (a.m + TAP_BM - 1) / TAP_BM;
-    hipLaunchKernelGGL((conv_tap_lds_kernel<KS, NRB>), dim3(mtiles * a.ntiles), dim3(256), shm, s, a);
+    hipLaunchKernelGGL((conv_tap_lds_kernel<KS, NRB>), dim3(((mtiles + 7) / 8) * 8 * a.ntiles), dim3(256), shm, s, a);
     return hipGetLastError();
 }
 

@@ -75,9 +75,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
     const int li = lane & 15, g = lane >> 4;
     // 1-D grid, cout tile fastest: the blocks that share an activation tile are dispatched together, so the
     // tile is fetched from HBM once and re-read from L2
+    // the hardware places block b on XCD b % 8 (private L2s): the cout tiles of one M tile are issued 8 ids apart
     const int ngroups = p.cout / (16 * NR);
-    const int ng = blockIdx.x % ngroups;
-    const int m0 = ((blockIdx.x / ngroups) * 4 + wave) * (16 * MR);
+    const int ng = (blockIdx.x >> 3) % ngroups;
+    const int mtile = (blockIdx.x / (8 * ngroups)) * 8 + (blockIdx.x & 7);
+    const int m0 = (mtile * 4 + wave) * (16 * MR);
+    if (mtile * 64 * MR >= p.m) return;
     const elem *__restrict__ in = (const elem *)p.in;
 
     long inrow[MR];
@@ -195,7 +198,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
 template <int DT, int NR>
 static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
     constexpr int MR = 4;
-    dim3 grid(((a.m + 64 * MR - 1) / (64 * MR)) * (a.cout / (16 * NR)));
+    const int mtiles = (a.m + 64 * MR - 1) / (64 * MR);
+    dim3 grid(((mtiles + 7) / 8) * 8 * (a.cout / (16 * NR)));
     hipLaunchKernelGGL((conv_direct_kernel<DT, NR, MR>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
