@@ -111,7 +111,7 @@ struct hrn_ctx {
     Conv3Problem *probs_dev = nullptr;
     std::vector<Op> ops;
     int stem_out_t = -1, head_in_t = -1;
-    int64_t stem_w_off = 0, stem_b_off = 0, head_w_off = 0, head_b_off = 0;
+    int64_t stem_w_off = 0, stem_b_off = 0, stem_wp_off = 0, head_w_off = 0, head_b_off = 0;
 
     int64_t blob_bytes = 0;
     char *blob = nullptr;  // device (or host when plan_only)
@@ -120,6 +120,7 @@ struct hrn_ctx {
     bool disable_lds = getenv("HRN_DISABLE_LDS") != nullptr;
     bool disable_group = getenv("HRN_DISABLE_GROUP") != nullptr;
     bool disable_tap = getenv("HRN_DISABLE_TAP") != nullptr;
+    bool disable_stem_mfma = getenv("HRN_DISABLE_STEM_MFMA") != nullptr;
     bool direct_nr6 = getenv("HRN_DIRECT_NR6") ? atoi(getenv("HRN_DIRECT_NR6")) != 0 : true;
     bool tap_stride2 = getenv("HRN_TAP_STRIDE2") != nullptr;  // stride-2 via the tap kernel (slower than direct so far)
     int half_stages_per_block = getenv("HRN_HALF_STAGES") ? atoi(getenv("HRN_HALF_STAGES")) : 8;
@@ -382,6 +383,7 @@ struct hrn_ctx {
         int64_t off = 0;
         stem_w_off = off, off = align_up(off + 27 * 64 * 4, 256);
         stem_b_off = off, off = align_up(off + 64 * 4, 256);
+        stem_wp_off = off, off = align_up(off + 4 * 1024, 256);  // bf16 MFMA image of conv1 (stem_mfma_kernel)
         for (auto &cv : convs) {
             cv.w_off = off;
             if (cv.algo == 2) {
@@ -615,6 +617,18 @@ struct hrn_ctx {
                 for (int k = 0; k < 27; ++k) dw[k * 64 + co] = (float)((double)w[co * 27 + k] * scale[co]);
                 db[co] = (float)shift[co];
             }
+            // MFMA image: one K chunk (k = ci*9 + kh*3 + kw, zero for k >= 27), 4 fragments, the usual cout
+            // permutation with NR = 4 (lane owns 16 contiguous channels)
+            uint16_t *dp = (uint16_t *)(host.data() + stem_wp_off);
+            for (int j = 0; j < 4; ++j)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int li = lane & 15, g = lane >> 4;
+                    const int co = (li >> 2) * 16 + j * 4 + (li & 3);
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = g * 8 + e;
+                        dp[(j * 64 + lane) * 8 + e] = f32_to_bf16_host(k < 27 ? (float)((double)w[co * 27 + k] * scale[co]) : 0.f);
+                    }
+                }
         }
         std::vector<float> wf;
         for (auto &cv : convs) {
@@ -754,6 +768,7 @@ struct hrn_ctx {
                     StemArgs a;
                     a.images = images, a.out = row0(stem_out_t);
                     a.w = (const float *)(blob + stem_w_off), a.bias = (const float *)(blob + stem_b_off);
+                    a.wp = (dtype == HRN_BF16 && !disable_stem_mfma) ? (const void *)(blob + stem_wp_off) : nullptr;
                     a.n = nb, a.H = H, a.W = W;
                     a.out_h = t.h, a.out_w = t.w, a.out_wp = t.wp, a.out_hpwp = t.hpwp;
                     e = launch_stem(dtype, a, s);

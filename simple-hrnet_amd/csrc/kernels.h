@@ -84,6 +84,7 @@ struct StemArgs {          // conv1 3->64 3x3 s2 + BN + ReLU, NCHW fp32 in, flat
     void *out;
     const float *w;        // [27][64] fp32, folded
     const float *bias;     // [64]
+    const void *wp;        // bf16 mode: MFMA image of the weights, [4 frags][64 lanes][8 bf16], K = 27 padded to 32
     int n, H, W;           // input size
     int out_h, out_w, out_wp, out_hpwp;
 };

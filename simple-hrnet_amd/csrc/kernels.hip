@@ -274,11 +274,80 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs p) {
     }
 }
 
+// bf16 mode: the same 3->64 stride-2 convolution on MFMA.  K = 27 (ci, kh, kw) padded to one 32-wide chunk; a
+// lane gathers its 8 k-values of one output pixel straight from the NCHW fp32 crop (rounded to bf16 -- every
+// later activation is bf16 as well), the 4 KiB weight image is held in registers, and one wave turns 64 pixels x
+// 64 channels with 16 MFMAs instead of 1728 scalar-weight FMAs per pixel.  Output: 32 contiguous bytes per lane.
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs p) {
+    constexpr int MR = 4, NR = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int m = p.n * p.out_hpwp;
+    const int q0 = (blockIdx.x * 4 + wave) * 64;
+    if (q0 >= m) return;
+    s16x8 wf[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) wf[j] = *(const s16x8 *)((const char *)p.wp + (j * 64 + lane) * 16);
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const f32x4 b = *(const f32x4 *)(p.bias + g * 4 * NR + j * 4);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) acc[i][j] = b;
+    }
+    // this lane's 8 taps: k = g*8 + e -> (ci, kh, kw); k >= 27 is zero padding
+    int dci[8], dkh[8], dkw[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = g * 8 + e;
+        dci[e] = k / 9, dkh[e] = (k % 9) / 3 - 1, dkw[e] = k % 3 - 1;
+    }
+    bool okp[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int q = q0 + i * 16 + li;
+        const int n = q / p.out_hpwp, rem = q - n * p.out_hpwp;
+        const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
+        okp[i] = q < m && ho < p.out_h && wo < p.out_w;
+        const float *img = p.images + (size_t)n * 3 * p.H * p.W;
+        s16x8 xf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int iy = 2 * ho + dkh[e], ix = 2 * wo + dkw[e];
+            float v = 0.f;
+            if (okp[i] && g * 8 + e < 27 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                v = img[((size_t)dci[e] * p.H + iy) * p.W + ix];
+            xf[e] = (short)f32_to_bf16(v);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = mma<DT_BF16>(wf[j], xf, acc[i][j]);
+    }
+    unsigned short *out = (unsigned short *)p.out;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int q = q0 + i * 16 + li;
+        if (q >= m) continue;
+        unsigned short *o = out + (size_t)q * 64 + g * 4 * NR;
+#pragma unroll
+        for (int j = 0; j < NR; j += 2) {
+            s16x8 o8;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float v = okp[i] ? fmaxf(acc[i][j + (r >> 2)][r & 3], 0.f) : 0.f;
+                o8[r] = (short)f32_to_bf16(v);
+            }
+            *(s16x8 *)(o + j * 4) = o8;
+        }
+    }
+}
+
 hipError_t launch_stem(int dtype, const StemArgs &a, hipStream_t s) {
     const int m = a.n * a.out_hpwp;
     if (m <= 0) return hipSuccess;
     dim3 grid((m + 255) / 256);
-    if (dtype == DT_BF16)
+    if (dtype == DT_BF16 && a.wp)
+        hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, s, a);
+    else if (dtype == DT_BF16)
         hipLaunchKernelGGL(stem_kernel<DT_BF16>, grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(stem_kernel<DT_F32>, grid, dim3(256), 0, s, a);
