@@ -75,6 +75,9 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, SALU M0
     const int li = lane & 15, g = lane >> 4;
+    // waves 4-7 are the younger wave of each SIMD and lose every issue arbitration to their partner (priority,
+    // then age): static priority for them evens the two out (cdna_hip_programming.md T5, static form)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int m = nb * p.hpwp;
     const int mtiles = (m + BM - 1) / BM;
     int ntile = mtiles - mt0;
