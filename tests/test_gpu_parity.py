@@ -202,3 +202,41 @@ def test_w32_config2_shape_batch64(pkg, dtype):
     hm_b, pts_b = net.predict_crops(torch.from_numpy(crops_np[::-1].copy()).cuda(), boxes[::-1].copy(), return_heatmaps=True)
     assert torch.equal(hm_b.flip(0), hm) and torch.equal(pts_b.flip(0), pts)
     net.close()
+
+
+def test_ragged_micro_batches_and_blockmap_rebuild(pkg):
+    """n not a multiple of max_batch: the tail pass runs with a different row count, which re-derives the block
+    maps of the grouped conv launches; alternate sizes back and forth and compare every crop with its
+    stand-alone result (bit-exact: a crop's arithmetic does not depend on its neighbours)."""
+    c, h, w = 48, 128, 96
+    net = _engine(pkg, c, h, w, "bf16", max_batch=8)
+    crops = torch.from_numpy(pkg.synth_crops(21, h, w, seed=31)).cuda()
+    boxes = pkg.synth_boxes(21, seed=31)
+    ref_hm, ref_pts = net.predict_crops(crops[:8], boxes[:8], return_heatmaps=True)
+    for n in (21, 1, 9, 8, 3, 21):
+        hm, pts = net.predict_crops(crops[:n], boxes[:n], return_heatmaps=True)
+        k = min(n, 8)
+        assert torch.equal(hm[:k], ref_hm[:k]) and torch.equal(pts[:k], ref_pts[:k]), n
+        if n == 21:  # crops 16..20 went through the tail pass (nb = 5): same bits as a batch that starts with them
+            hm2, pts2 = net.predict_crops(crops[16:21], boxes[16:21], return_heatmaps=True)
+            assert torch.equal(hm[16:], hm2) and torch.equal(pts[16:], pts2)
+    net.close()
+
+
+def test_repeatability_full_size(pkg):
+    """race screen for the hand-scheduled kernels (inline-asm LDS reads, counted waits, LDS-DMA pipeline):
+    300 W48 384x288 crops, micro-batch 256, three runs must agree bit for bit."""
+    c, h, w, n = 48, 384, 288, 300
+    net = _engine(pkg, c, h, w, "bf16", max_batch=256)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    crops = torch.randn((n, 3, h, w), generator=g, device="cuda")
+    boxes = pkg.synth_boxes(n, seed=5)
+    hm0, p0 = net.predict_crops(crops, boxes, return_heatmaps=True)
+    for _ in range(2):
+        hm, p = net.predict_crops(crops, boxes, return_heatmaps=True)
+        assert torch.equal(hm, hm0) and torch.equal(p, p0)
+    # the first 44 crops of the tail pass (nb = 44) equal the same crops run on their own
+    hm_t, p_t = net.predict_crops(crops[256:], boxes[256:], return_heatmaps=True)
+    assert torch.equal(hm_t, hm0[256:]) and torch.equal(p_t, p0[256:])
+    assert bool(torch.isfinite(hm0).all())
+    net.close()
