@@ -54,10 +54,25 @@ __device__ __forceinline__ void glds16(const GLOBAL_AS void *gsrc, char *lds_wav
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-constexpr int C3_KS = 48, C3_NRB = 3, C3_NCH = 14, C3_HCH = 7;   // chunks per slice / per half
-constexpr int C3_WHALF = C3_HCH * C3_NRB * 1024;                 // 21504 B
-constexpr int C3_SLAB = 57344;                                   // one slab buffer (>= (512+2*37+2)*96)
-constexpr int C3_LDS = 2 * C3_WHALF + 2 * C3_SLAB;               // 157696 B
+// Kernel configurations.  KS = 48 (HRNet-W48 branches): 96-byte slab pitch, a slice = 14 chunks in two parts of 7.
+// KS = 32 (HRNet-W32 branches, layer1's 64->64, transition1's 256->48): 64-byte pitch with the 16-byte slots
+// XOR-swizzled by 2*((row>>2)&1) (conflict-free for any 16 consecutive rows), a slice = 9 chunks (one per tap, no
+// K padding) in a single part.  LDS = 2 weight part buffers + 2 slab buffers <= 160 KiB.
+template <int KS_, int NRB_>
+struct C3Cfg {
+    static constexpr int KS = KS_, NRB = NRB_;
+    static constexpr int PARTS = KS == 48 ? 2 : 1;            // parts per slice
+    static constexpr int CPP = KS == 48 ? 7 : 9;              // chunks per part
+    static constexpr int NCH = PARTS * CPP;                   // chunks per slice
+    static constexpr int WPART = CPP * NRB * 1024;            // bytes of one weight part
+    static constexpr int SLAB = KS == 48 ? 57344 : 43008;     // one slab buffer
+    static constexpr int LDS = 2 * WPART + 2 * SLAB;
+    static constexpr int ROWB = KS * 2;
+    static constexpr int MAXROWS = SLAB / ROWB;               // slab rows that fit
+    static constexpr int NWP = (WPART / 16 + 511) / 512;      // LDS-DMA pieces per wave for one weight part
+    static constexpr int NSP = (SLAB / 16 + 511) / 512;       // ... for one slab
+    static_assert(LDS <= 160 * 1024 - 256, "LDS budget");
+};
 
 #ifdef HRN_C3_TIMING
 #define C3_T(x) const long long x = __builtin_amdgcn_s_memtime()
@@ -66,12 +81,13 @@ __device__ long long *g_c3_timing = nullptr;
 #define C3_T(x)
 #endif
 
-template <int MR>
+template <class CFG, int MR>
 __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, const int mt0, const int nb,
                                           char *smem) {
-    constexpr int KS = C3_KS, NRB = C3_NRB, ROWB = KS * 2, UPR = KS / 8, NT = 512;
+    constexpr int KS = CFG::KS, NRB = CFG::NRB, ROWB = CFG::ROWB, UPR = KS / 8, NT = 512;
     constexpr int BM = 128 * MR;
-    constexpr int SLAB_ITERS = C3_SLAB / 16 / NT;  // max LDS-DMA instructions per wave per slab (7)
+    constexpr int PARTS = CFG::PARTS, CPP = CFG::CPP, NCH = CFG::NCH, WPART = CFG::WPART, SLABB = CFG::SLAB;
+    constexpr int NWP = CFG::NWP, SLAB_ITERS = CFG::NSP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, SALU M0
     const int li = lane & 15, g = lane >> 4;
@@ -87,18 +103,21 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
     const int slab_units = (BM + 2 * p.wp + 2) * UPR;
     const gcu16 in = (gcu16)p.in;
     char *const wbuf = smem;
-    char *const sbuf = smem + 2 * C3_WHALF;
+    char *const sbuf = smem + 2 * WPART;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;  // LDS byte address
 
     // per-lane LDS byte offset of k-group g of chunk c, relative to the lane's own pixel row in the slab
-    int xoff[C3_NCH];
+    int xoff[NCH];
 #pragma unroll
-    for (int c = 0; c < C3_NCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         int k0 = 32 * c + 8 * g;
         if (k0 >= 9 * KS) k0 = 0;  // zero-weight padding: any valid slab address
         const int tap = k0 / KS, ci = k0 - tap * KS;
         const int dh = tap / 3, dw = tap - 3 * dh;
-        xoff[c] = (dh * p.wp + dw) * ROWB + ci * 2;
+        const int shift = dh * p.wp + dw;
+        int slot = ci >> 3;
+        if (KS == 32) slot ^= (((wave * 16 * MR + li + shift) >> 2) & 1) << 1;  // + 16*i rows leaves bit 2 alone
+        xoff[c] = shift * ROWB + slot * 16;
     }
     const int xrow0 = (wave * 16 * MR + li) * ROWB;
     // per-lane element offset of the k-th slab LDS-DMA piece relative to the slab's first row
@@ -107,7 +126,9 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
     for (int k = 0; k < SLAB_ITERS; ++k) {
         int u = k * NT + tid;
         if (u >= slab_units) u = slab_units - 1;  // tail lanes re-read a valid unit; LDS has room for them
-        const int r = u / UPR, q = u - r * UPR;
+        const int r = u / UPR;
+        int q = u - r * UPR;
+        if (KS == 32) q ^= ((r >> 2) & 1) << 1;  // swizzled image: LDS slot u % 4 of row r holds source slot q
         srel[k] = (unsigned)(r * p.cin + q * 8) * 2u;  // bytes
     }
 
@@ -118,7 +139,7 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
     const gu16 out = (gu16)p.out;
     const gcu16 res = (gcu16)p.res;
     const bool has_res = p.res != nullptr;
-    const GLOBAL_AS char *const wsrc_nt = (const GLOBAL_AS char *)p.w + (size_t)nt * S * (2 * C3_WHALF);
+    const GLOBAL_AS char *const wsrc_nt = (const GLOBAL_AS char *)p.w + (size_t)nt * S * (PARTS * WPART);
 
     // The LDS-DMA of half-stage (tt, s, hf) is cut into per-wave "pieces" (one 1 KiB instruction each):
     // pieces 0..2 = this wave's share of the weight half -> wbuf[hf]; pieces 3..9 = its share of the slab of
@@ -129,7 +150,8 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
 #endif
     // piece counts of THIS wave (wave-uniform; plain scalars -- a counter bumped inside the lambdas ends up in
     // scratch memory, and every scratch access is a VMEM op that drains the LDS-DMA queue with vmcnt(0))
-    const int nw_wave = wave < 5 ? 3 : 2;                       // 1344 weight units / (512 per piece row)
+    int nw_wave = (WPART / 16 - wave * 64 + NT - 1) / NT;         // weight pieces: k*512 + wave*64 < WPART/16
+    nw_wave = nw_wave < 0 ? 0 : (nw_wave > NWP ? NWP : nw_wave);
     int ns_wave = (slab_units - wave * 64 + NT - 1) / NT;       // slab pieces: k*512 + wave*64 < slab_units
     ns_wave = ns_wave < 0 ? 0 : (ns_wave > SLAB_ITERS ? SLAB_ITERS : ns_wave);
     int npost = 0;  // LDS-DMA instructions issued after the residual request (last half-stage of a tile)
@@ -140,40 +162,43 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
         const GLOBAL_AS char *ssrc;   // nullptr: no slab in this half-stage
         char *sdst;
     };
-    // weights of half-stage (tt, s, hf) -> wbuf[hf]   (single-slice problems keep both halves resident)
-    auto plan_w = [&](Next &n, int tt, int s, int hf) {
-        n.wsrc = (S > 1 || tt == 0) ? wsrc_nt + (size_t)(2 * s + hf) * C3_WHALF : nullptr;
-        n.wdst = wbuf + hf * C3_WHALF;
+    // weights of part (tt, s, part) -> wbuf[buf]   (single-slice problems keep all their parts resident)
+    auto plan_w = [&](Next &n, int tt, int s, int part, int buf) {
+        n.wsrc = (S > 1 || tt == 0) ? wsrc_nt + (size_t)(PARTS * s + part) * WPART : nullptr;
+        n.wdst = wbuf + buf * WPART;
     };
     // slab of (tile tt, slice s) -> sbuf[par]
     auto plan_s = [&](Next &n, int tt, int s, int par) {
         const long row0 = (long)(mt0 + tt) * BM - p.wp - 1;  // guard rows make negative / overrun rows valid
         n.ssrc = (const GLOBAL_AS char *)(in + row0 * p.cin + s * KS);
-        n.sdst = sbuf + par * C3_SLAB + wave * 1024;
+        n.sdst = sbuf + par * SLABB + wave * 1024;
     };
     auto piece = [&](const Next &n, int idx) {
 #ifdef HRN_C3_NODMA  // ablation build (tools/c3_timing.py): results are garbage, only the timing is of interest
         if (tt_guard) return;
 #endif
-        if (idx < 3) {
+        if (idx < NWP) {
             const int u0 = idx * NT + wave * 64;
-            if (n.wsrc && u0 < C3_WHALF / 16) {
+            if (n.wsrc && u0 < WPART / 16) {
                 glds16(n.wsrc + (size_t)(u0 + lane) * 16, n.wdst + u0 * 16);
             }
         } else {
-            const int k = idx - 3;
+            const int k = idx - NWP;
             if (n.ssrc && k * NT + wave * 64 < slab_units) {
                 glds16(n.ssrc + srel[k], n.sdst + k * NT * 16);
             }
         }
     };
-    constexpr int NPIECE = 3 + SLAB_ITERS;
+    constexpr int NPIECE = NWP + SLAB_ITERS;
+    constexpr int PPC = (NPIECE + 3) / 4;  // pieces per chunk: a wave spreads its pieces over four chunks
 
     f32x4 acc[MR][NRB];
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    u32x4 rpre4[MR];   // residual channels 0..7 of the lane's 12
-    u32x2 rpre2[MR];   // residual channels 8..11
+    constexpr int N16 = NRB / 2;       // 16-byte pieces of the lane's 4*NRB contiguous channels, plus 8 bytes if NRB is odd
+    u32x4 rpre4[MR][N16 ? N16 : 1];
+    u32x2 rpre2[MR];
+    int wcount = 0;  // parts executed so far (selects the weight buffer when a slice is a single part)
     bool after_epilogue = false;
     int slab_par = 0;
 #ifdef HRN_C3_TIMING
@@ -183,7 +208,7 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
 #endif
     {
         Next n0;
-        plan_w(n0, 0, 0, 0);
+        plan_w(n0, 0, 0, 0, 0);
         plan_s(n0, 0, 0, 0);
 #pragma unroll
         for (int k = 0; k < NPIECE; ++k) piece(n0, k);
@@ -195,11 +220,11 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
             for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{bias[j * 4], bias[j * 4 + 1], bias[j * 4 + 2], bias[j * 4 + 3]};
         for (int s = 0; s < S; ++s) {
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
+            for (int hf = 0; hf < PARTS; ++hf) {  // hf = part of the slice
                 C3_T(tA);
                 // this wave's LDS-DMA for this half-stage has landed.  vmcnt retires in order and counts stores:
                 // right after an epilogue the youngest 2*MR operations are its stores, which may stay in flight
-                if (hf == 1) {
+                if (PARTS == 2 && hf == 1) {
                     // the youngest `nslab` operations are the NEXT slice's slab pieces (issued during hf == 0,
                     // after this half-stage's weights): they get a second half-stage to land
                     switch (nslab) {
@@ -213,7 +238,7 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                         default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
                     }
                 } else if (after_epilogue) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MR * 2) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(MR * (N16 + (NRB & 1))) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -225,20 +250,31 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                 //      hf == 1: the weights of the next slice's first half.
                 Next nx;
                 nx.wsrc = nullptr, nx.ssrc = nullptr, nx.wdst = wbuf, nx.sdst = sbuf;
+                // weight buffer of the current part: two-part slices alternate by part; one-part slices alternate by
+                // a running count (a single-slice, single-part problem keeps its weights in buffer 0)
+                const int wcur = PARTS == 2 ? hf : (S == 1 ? 0 : (wcount & 1));
                 {
                     int s2 = s + 1, t2 = tt;
                     if (s2 == S) s2 = 0, ++t2;
-                    if (hf == 0) {
-                        plan_w(nx, tt, s, 1);
-                        if (t2 < ntile) plan_s(nx, t2, s2, slab_par ^ 1);
-                        nslab = nx.ssrc ? ns_wave : 0;
+                    if (PARTS == 2) {
+                        if (hf == 0) {
+                            plan_w(nx, tt, s, 1, 1);
+                            if (t2 < ntile) plan_s(nx, t2, s2, slab_par ^ 1);
+                            nslab = nx.ssrc ? ns_wave : 0;
+                        } else {
+                            if (t2 < ntile) plan_w(nx, t2, s2, 0, 0);
+                            npost = nx.wsrc ? nw_wave : 0;
+                        }
+                    } else if (t2 < ntile) {  // one part per slice: next slice's weights and slab together
+                        plan_w(nx, t2, s2, 0, S == 1 ? 0 : (wcur ^ 1));
+                        plan_s(nx, t2, s2, slab_par ^ 1);
+                        npost = (nx.wsrc ? nw_wave : 0) + ns_wave;
                     } else {
-                        if (t2 < ntile) plan_w(nx, t2, s2, 0);
-                        npost = nx.wsrc ? nw_wave : 0;
+                        npost = 0;
                     }
                 }
                 // ---- last half-stage of the tile: request the residual tile now, it lands under the MFMAs
-                if (hf == 1 && s == S - 1) {
+                if (hf == PARTS - 1 && s == S - 1) {
                     const int p0r = (mt0 + tt) * BM + wave * 16 * MR + li;
                     if (has_res) {
 #pragma unroll
@@ -246,50 +282,58 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                             int q = p0r + i * 16;
                             if (q >= m) q = 0;
                             const gcu16 rp = res + (size_t)q * p.cout + ch0;
-                            // hand-issued (two instructions per fragment): waited for with a COUNTED vmcnt in the epilogue
-                            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rpre4[i]) : "v"(rp));
-                            asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=v"(rpre2[i]) : "v"(rp));
+                            // hand-issued loads: waited for with a COUNTED vmcnt in the epilogue
+#pragma unroll
+                            for (int v = 0; v < N16; ++v)
+                                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(rpre4[i][v]) : "v"(rp), "i"(v * 16));
+                            if (NRB & 1)
+                                asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(rpre2[i]) : "v"(rp), "i"(N16 * 16));
                         }
                     } else {
 #pragma unroll
-                        for (int i = 0; i < MR; ++i)
-                            rpre4[i] = u32x4{0u, 0u, 0u, 0u}, rpre2[i] = u32x2{0u, 0u};
+                        for (int i = 0; i < MR; ++i) {
+#pragma unroll
+                            for (int v = 0; v < (N16 ? N16 : 1); ++v) rpre4[i][v] = u32x4{0u, 0u, 0u, 0u};
+                            rpre2[i] = u32x2{0u, 0u};
+                        }
                     }
                 }
                 C3_T(tC);
-                // ---- compute 7 chunks of K = 32 from wbuf[hf] and the current slab
+                // ---- compute the CPP chunks of K = 32 of this part from wbuf[wcur] and the current slab
                 // Fragment reads are issued by hand (inline asm) one chunk ahead, with COUNTED waits: hipcc would
                 // drain lgkmcnt(0) in front of every other MFMA block here, stalling on reads it has just issued.
                 // Order is pinned with sched_barrier(0) (an MFMA must not be hoisted above the wait that covers
                 // its operands; cdna_hip_programming.md rule 18).
                 s16x8 wf[2][NRB], xf[2][MR];
-                const unsigned wl_a = lds0 + hf * C3_WHALF + lane * 16;
-                const unsigned sl_a = lds0 + 2 * C3_WHALF + slab_par * C3_SLAB + xrow0;
+                const unsigned wl_a = lds0 + wcur * WPART + lane * 16;
+                const unsigned sl_a = lds0 + 2 * WPART + slab_par * SLABB + xrow0;
 #define C3_READ_CHUNK(SET, C)                                                                                  \
     {                                                                                                          \
         _Pragma("unroll") for (int j = 0; j < NRB; ++j)                                                        \
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[SET][j]) : "v"(wl_a), "i"(((C)*NRB + j) * 1024)); \
-        const unsigned xa = sl_a + xoff[hf * C3_HCH + (C)];                                                    \
+        const unsigned xa = sl_a + xoff[hf * CPP + (C)];                                                    \
         _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                         \
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[SET][i]) : "v"(xa), "i"(i * 16 * ROWB));    \
     }
                 C3_READ_CHUNK(0, 0)
 #pragma unroll
-                for (int c = 0; c < C3_HCH; ++c) {
+                for (int c = 0; c < CPP; ++c) {
                     const int cur = c & 1, nxt = cur ^ 1;
-                    if (c + 1 < C3_HCH) {
+                    if (c + 1 < CPP) {
                         C3_READ_CHUNK(nxt, c + 1)
                     }
                     // the two waves of a SIMD (w, w+4) issue their LDS-DMA pieces in different chunks
                     {
-                        const int c0 = wave < 4 ? c : c - 3;   // waves 0-3: chunks 0..3, waves 4-7: chunks 3..6
+                        const int c0 = wave < 4 ? c : c - (CPP - 4);   // waves 0-3: chunks 0..3, waves 4-7: the last four
                         if (c0 >= 0 && c0 < 4) {
-                            if (3 * c0 < NPIECE) piece(nx, 3 * c0);
-                            if (3 * c0 + 1 < NPIECE) piece(nx, 3 * c0 + 1);
-                            if (3 * c0 + 2 < NPIECE) piece(nx, 3 * c0 + 2);
+                            // (written out: as a loop hipcc spills 18 VGPRs to scratch here)
+                            static_assert(PPC <= 3, "pieces per chunk");
+                            if (PPC * c0 < NPIECE) piece(nx, PPC * c0);
+                            if (PPC > 1 && PPC * c0 + 1 < NPIECE) piece(nx, PPC * c0 + 1);
+                            if (PPC > 2 && PPC * c0 + 2 < NPIECE) piece(nx, PPC * c0 + 2);
                         }
                     }
-                    if (c + 1 < C3_HCH)
+                    if (c + 1 < CPP)
                         asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(NRB + MR) : "memory");  // chunk c landed, c+1 in flight
                     else
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -308,7 +352,8 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                 C3_T(tD);
                 t_wait += tB - tA, t_issue += tC - tB, t_comp += tD - tC, ++n_half;
 #endif
-                if (hf == 1) slab_par ^= 1;
+                ++wcount;
+                if (hf == PARTS - 1) slab_par ^= 1;
             }
         }
         // ---- epilogue: + bias (+ residual) (ReLU), zero on pad pixels; lane owns 12 contiguous channels
@@ -326,7 +371,7 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                 case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
                 case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
                 case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;  // stricter than needed: safe
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -344,7 +389,8 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
 #pragma unroll
             for (int j = 0; j < NRB; ++j) {
                 // residual: two bf16 per dword -> fp32 with one shift / one mask each
-                const unsigned r01 = j < 2 ? rpre4[i][2 * j] : rpre2[i][0], r23 = j < 2 ? rpre4[i][2 * j + 1] : rpre2[i][1];
+                const unsigned r01 = (j >> 1) < N16 ? rpre4[i][(j >> 1) < N16 ? (j >> 1) : 0][2 * (j & 1)] : rpre2[i][0];
+                const unsigned r23 = (j >> 1) < N16 ? rpre4[i][(j >> 1) < N16 ? (j >> 1) : 0][2 * (j & 1) + 1] : rpre2[i][1];
                 float v0 = acc[i][j][0] + __uint_as_float(r01 << 16);
                 float v1 = acc[i][j][1] + __uint_as_float(r01 & 0xffff0000u);
                 float v2 = acc[i][j][2] + __uint_as_float(r23 << 16);
@@ -355,9 +401,12 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                 pk[2 * j] = ok ? __builtin_bit_cast(unsigned, lo) : 0u;
                 pk[2 * j + 1] = ok ? __builtin_bit_cast(unsigned, hi) : 0u;
             }
-            // 24 contiguous bytes per lane: one 16-byte + one 8-byte store (store issue count is what the tail costs)
-            *(GLOBAL_AS u32x4 *)(out + o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-            *(GLOBAL_AS u32x2 *)(out + o + 8) = u32x2{pk[4], pk[5]};
+            // 8*NRB contiguous bytes per lane in 16-byte stores (+ one 8-byte store when NRB is odd): the store
+            // issue count is what the tail costs
+#pragma unroll
+            for (int v = 0; v < N16; ++v)
+                *(GLOBAL_AS u32x4 *)(out + o + v * 8) = u32x4{pk[4 * v], pk[4 * v + 1], pk[4 * v + 2], pk[4 * v + 3]};
+            if (NRB & 1) *(GLOBAL_AS u32x2 *)(out + o + N16 * 8) = u32x2{pk[4 * N16], pk[4 * N16 + 1]};
         }
         after_epilogue = true;
 #ifdef HRN_C3_TIMING
@@ -375,15 +424,21 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
 #endif
 }
 
+template <int KS, int NRB>
 __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem *__restrict__ probs,
                                                              const int2 *__restrict__ blockmap, const int nb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using CFG = C3Cfg<KS, NRB>;
     const int2 bm = blockmap[blockIdx.x];
     const Conv3Problem p = probs[bm.x & 0xff];
-    if (p.bm == 512)
-        conv3_run<4>(p, bm.x >> 8, bm.y, nb, smem);
-    else
-        conv3_run<3>(p, bm.x >> 8, bm.y, nb, smem);  // bm == 384
+    if constexpr (NRB == 4) {  // 64 accumulator + 64 fragment registers at MR = 4 would spill: 384-pixel tiles only
+        conv3_run<CFG, 3>(p, bm.x >> 8, bm.y, nb, smem);
+    } else {
+        if (p.bm == 512)
+            conv3_run<CFG, 4>(p, bm.x >> 8, bm.y, nb, smem);
+        else
+            conv3_run<CFG, 3>(p, bm.x >> 8, bm.y, nb, smem);  // bm == 384
+    }
 }
 
 #ifdef HRN_C3_TIMING
@@ -402,21 +457,37 @@ extern "C" int hrn_debug_c3_timing(long long *host_out, int max_blocks) {
 }
 #endif
 
-int conv3x3_lds_bm(int wp) { return (512 + 2 * wp + 2) * 96 <= C3_SLAB ? 512 : 384; }
-
-hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb,
-                              hipStream_t s) {
-    if (nblocks <= 0) return hipSuccess;
+template <int KS, int NRB>
+static hipError_t launch_c3(const Conv3Problem *probs_dev, const int2 *blockmap_dev, int nblocks, int nb, hipStream_t s) {
+    using CFG = C3Cfg<KS, NRB>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv3x3_lds_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS);
+        hipError_t e = hipFuncSetAttribute((const void *)conv3x3_lds_kernel<KS, NRB>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_lds_kernel, dim3(nblocks), dim3(512), C3_LDS, s, probs_dev, (const int2 *)blockmap_dev,
-                       nb);
+    hipLaunchKernelGGL((conv3x3_lds_kernel<KS, NRB>), dim3(nblocks), dim3(512), CFG::LDS, s, probs_dev, blockmap_dev, nb);
     return hipGetLastError();
+}
+
+// pixels per M tile for a (KS, wp) pair: 512, or 384 when two 512-row slabs (+ halo) would not fit in LDS; 0 = unsupported
+int conv3x3_lds_bm(int ks, int nrb, int wp) {
+    const int maxrows = ks == 48 ? C3Cfg<48, 3>::MAXROWS : C3Cfg<32, 4>::MAXROWS;
+    if (nrb != 4 && 512 + 2 * wp + 2 <= maxrows) return 512;
+    if (384 + 2 * wp + 2 <= maxrows) return 384;
+    return 0;
+}
+
+hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb, int ks,
+                              int nrb, hipStream_t s) {
+    if (nblocks <= 0) return hipSuccess;
+    const int2 *bm = (const int2 *)blockmap_dev;
+    if (ks == 48 && nrb == 3) return launch_c3<48, 3>(probs_dev, bm, nblocks, nb, s);
+    if (ks == 32 && nrb == 4) return launch_c3<32, 4>(probs_dev, bm, nblocks, nb, s);
+    if (ks == 32 && nrb == 3) return launch_c3<32, 3>(probs_dev, bm, nblocks, nb, s);
+    if (ks == 32 && nrb == 2) return launch_c3<32, 2>(probs_dev, bm, nblocks, nb, s);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace hrn

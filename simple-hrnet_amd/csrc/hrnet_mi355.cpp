@@ -120,6 +120,7 @@ struct hrn_ctx {
     bool disable_lds = getenv("HRN_DISABLE_LDS") != nullptr;
     bool disable_group = getenv("HRN_DISABLE_GROUP") != nullptr;
     bool disable_tap = getenv("HRN_DISABLE_TAP") != nullptr;
+    bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
     bool disable_stem_mfma = getenv("HRN_DISABLE_STEM_MFMA") != nullptr;
     bool direct_nr6 = getenv("HRN_DIRECT_NR6") ? atoi(getenv("HRN_DIRECT_NR6")) != 0 : true;
     bool tap_stride2 = getenv("HRN_TAP_STRIDE2") != nullptr;  // stride-2 via the tap kernel (slower than direct so far)
@@ -170,16 +171,26 @@ struct hrn_ctx {
         op.nr = (cout % 64 == 0) ? 4 : (cout % 48 == 0) ? 3 : 2;
         if (dtype == HRN_BF16 && stride == 2 && cout % 96 == 0 && direct_nr6) op.nr = 6;  // halves the A gathers per MFMA
         op.flops = 2.0 * cout * (double)K * oh * ow;
-        if (dtype == HRN_BF16 && k == 3 && stride == 1 && op.cin % 48 == 0 && cout % 48 == 0 && !disable_lds) {
-            op.algo = 1, op.ks = 48, op.nr = 3;
-            op.slices = op.cin / 48, op.ntiles = cout / 48, op.nch = (9 * 48 + 31) / 32;
+        // pipelined LDS kernel (conv3x3_lds.hip): KS = 48 / 48-cout tiles for the HRNet-W48 branch widths, KS = 32 with
+        // 64-, 48- or 32-cout tiles for everything else whose channel counts are multiples of 32
+        int lds_ks = 0, lds_nrb = 0;
+        if (dtype == HRN_BF16 && k == 3 && stride == 1 && !disable_lds) {
+            if (op.cin % 48 == 0 && cout % 48 == 0)
+                lds_ks = 48, lds_nrb = 3;
+            else if (op.cin % 32 == 0 && !disable_lds32)
+                lds_ks = 32, lds_nrb = cout % 64 == 0 ? 4 : cout % 48 == 0 ? 3 : cout % 32 == 0 ? 2 : 0;
+            if (lds_nrb && conv3x3_lds_bm(lds_ks, lds_nrb, ow + 1) == 0) lds_nrb = 0;
+        }
+        if (lds_nrb) {
+            op.algo = 1, op.ks = lds_ks, op.nr = lds_nrb;
+            op.slices = op.cin / lds_ks, op.ntiles = cout / (16 * lds_nrb), op.nch = (9 * lds_ks + 31) / 32;
             op.kpad = op.nch * 32 * op.slices;
         } else if (dtype == HRN_BF16 && k == 3 && (op.cin % 48 == 0 || op.cin % 32 == 0) &&
                    (cout % 64 == 0 || cout % 48 == 0) && !disable_tap && (stride == 1 || tap_stride2)) {
             build_tap_slices(op, ti, oh, ow);
         }
         convs.push_back(op);
-        if (emit) ops.push_back({OP_CONV, (int)convs.size() - 1});
+        if (emit) emit_convs({(int)convs.size() - 1});
         return op.out_t;
     }
 
@@ -252,11 +263,18 @@ struct hrn_ctx {
                 ops.push_back({OP_CONV, i});
         }
         if (lds.empty()) return;
-        std::vector<std::vector<int>> sets;
-        if (disable_group)
-            for (int i : lds) sets.push_back({i});
-        else
-            sets.push_back(lds);
+        std::vector<std::vector<int>> sets;  // one launch per (KS, NRB) configuration
+        for (int i : lds) {
+            bool placed = false;
+            if (!disable_group)
+                for (auto &set : sets)
+                    if (convs[set[0]].ks == convs[i].ks && convs[set[0]].nr == convs[i].nr) {
+                        set.push_back(i);
+                        placed = true;
+                        break;
+                    }
+            if (!placed) sets.push_back({i});
+        }
         for (auto &set : sets) {
             Conv3Group g;
             g.conv_idx = set;
@@ -441,7 +459,7 @@ struct hrn_ctx {
 
     // every block walks ~`half_stages_per_block` half-slices so that blocks of all branches last alike
     int conv3_tiles_per_block(const ConvOp &cv) const {
-        const int t = half_stages_per_block / (2 * cv.slices);
+        const int t = half_stages_per_block / ((cv.ks == 48 ? 2 : 1) * cv.slices);
         return t < 1 ? 1 : t;
     }
 
@@ -455,7 +473,7 @@ struct hrn_ctx {
         for (size_t k = 0; k < g.conv_idx.size(); ++k) {
             const ConvOp &cv = convs[g.conv_idx[k]];
             const Tensor &to = tensors[cv.out_t];
-            const int bm = conv3x3_lds_bm(to.wp);
+            const int bm = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
             const int mtiles = (nb * to.hpwp + bm - 1) / bm;
             const int tpb = conv3_tiles_per_block(cv);
             const int mgroups = (mtiles + tpb - 1) / tpb;
@@ -522,7 +540,7 @@ struct hrn_ctx {
                 q.cin = cv.cin, q.cout = cv.cout, q.h = to.h, q.wd = to.w, q.wp = to.wp, q.hpwp = to.hpwp;
                 q.relu = cv.relu, q.slices = cv.slices, q.ntiles = cv.ntiles;
                 q.tiles_per_block = conv3_tiles_per_block(cv);
-                q.bm = conv3x3_lds_bm(to.wp);
+                q.bm = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
                 fast_div(to.hpwp, &q.magic_hpwp, &q.shift_hpwp);
                 fast_div(to.wp, &q.magic_wp, &q.shift_wp);
                 if (to.wp > g.max_wp) g.max_wp = to.wp;
@@ -814,7 +832,8 @@ struct hrn_ctx {
                         if (e != hipSuccess) break;
                         g.cached_nb = nb;
                     }
-                    e = launch_conv3x3_lds(probs_dev + g.prob_first, g.map_dev, g.nblocks, nb, s);
+                    e = launch_conv3x3_lds(probs_dev + g.prob_first, g.map_dev, g.nblocks, nb, convs[g.conv_idx[0]].ks,
+                                           convs[g.conv_idx[0]].nr, s);
                     break;
                 }
                 case OP_FUSE: {

@@ -46,7 +46,7 @@ struct Conv3Problem {
     unsigned magic_hpwp, magic_wp;
     int shift_hpwp, shift_wp;
 };
-int conv3x3_lds_bm(int wp);
+int conv3x3_lds_bm(int ks, int nrb, int wp);
 
 // Tap-list LDS-staged 3x3 convolution (conv_tap_lds.hip): stride-2 convs and stride-1 convs outside the
 // BasicBlock shapes.  One K slice = (source view, channel range, tap list).
@@ -122,8 +122,8 @@ struct DecodeArgs {        // SimpleHRNet.py:297-308
 };
 
 hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s);
-hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb,
-                              hipStream_t s);
+hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb, int ks,
+                              int nrb, hipStream_t s);
 hipError_t launch_stem(int dtype, const StemArgs &a, hipStream_t s);
 hipError_t launch_fuse(int dtype, const FuseArgs &a, hipStream_t s);
 hipError_t launch_head(int dtype, const HeadArgs &a, hipStream_t s);
