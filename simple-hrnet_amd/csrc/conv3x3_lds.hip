@@ -48,6 +48,13 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     return (unsigned short)(u >> 16);
 }
 
+// ReLU as ONE v_max_f32: fmaxf() makes hipcc emit a canonicalising v_max in front of the real one
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ void glds16(const GLOBAL_AS void *gsrc, char *lds_wave_base) {
     // 64 lanes x 16 B -> LDS [lds_wave_base + lane*16); the base must be wave-uniform
     __builtin_amdgcn_global_load_lds(gsrc,
@@ -395,7 +402,7 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                 float v1 = acc[i][j][1] + __uint_as_float(r01 & 0xffff0000u);
                 float v2 = acc[i][j][2] + __uint_as_float(r23 << 16);
                 float v3 = acc[i][j][3] + __uint_as_float(r23 & 0xffff0000u);
-                if (p.relu) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f), v2 = fmaxf(v2, 0.f), v3 = fmaxf(v3, 0.f);
+                if (p.relu) v0 = relu1(v0), v1 = relu1(v1), v2 = relu1(v2), v3 = relu1(v3);
                 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
                 const bf16x2 lo = {(__bf16)v0, (__bf16)v1}, hi = {(__bf16)v2, (__bf16)v3};  // RNE, v_cvt_pk_bf16_f32
                 pk[2 * j] = ok ? __builtin_bit_cast(unsigned, lo) : 0u;
