@@ -1,0 +1,17 @@
+"""Latency of small calls (BASELINE configs[0] shape: 3 person crops, W32 256x192)."""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+pkg = importlib.import_module("simple-hrnet_amd")
+for c, h, w in ((32, 256, 192), (48, 384, 288)):
+    for dtype in ("fp32", "bf16"):
+        net = pkg.NativeHRNet(c, 17, (h, w), dtype, max_batch=32, device=0).load_state_dict(pkg.synth_state_dict(c, 17, 0))
+        for n in (1, 3, 16):
+            x = torch.randn((n, 3, h, w), device="cuda")
+            b = torch.from_numpy(pkg.synth_boxes(n)).cuda()
+            for _ in range(5): net.predict_crops(x, b)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(20): net.predict_crops(x, b)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+            print("W%d %dx%d %s n=%d: %.2f ms per call (%.0f crops/s), %d launches" % (c, h, w, dtype, n, dt * 1e3, n / dt, net.launches_per_pass()))
+        net.close()
