@@ -89,8 +89,8 @@ __device__ long long *g_c3_timing = nullptr;
 #endif
 
 template <class CFG, int MR>
-__device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, const int mt0, const int nb,
-                                          char *smem) {
+__device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, const int mt0, const int tiles_this_block,
+                                          const int nb, char *smem) {
     constexpr int KS = CFG::KS, NRB = CFG::NRB, ROWB = CFG::ROWB, UPR = KS / 8, NT = 512;
     constexpr int BM = 128 * MR;
     constexpr int PARTS = CFG::PARTS, CPP = CFG::CPP, NCH = CFG::NCH, WPART = CFG::WPART, SLABB = CFG::SLAB;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
     const int m = nb * p.hpwp;
     const int mtiles = (m + BM - 1) / BM;
     int ntile = mtiles - mt0;
-    if (ntile > p.tiles_per_block) ntile = p.tiles_per_block;
+    if (ntile > tiles_this_block) ntile = tiles_this_block;
     if (ntile <= 0) return;
     const int S = p.slices;
     const int slab_units = (BM + 2 * p.wp + 2) * UPR;
@@ -437,14 +437,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using CFG = C3Cfg<KS, NRB>;
     const int2 bm = blockmap[blockIdx.x];
+    // block map entry: x = problem | cout tile << 8 | M tiles of this block << 16,  y = first M tile
     const Conv3Problem p = probs[bm.x & 0xff];
+    const int nt = (bm.x >> 8) & 0xff, tiles = bm.x >> 16;
     if constexpr (NRB == 4) {  // 64 accumulator + 64 fragment registers at MR = 4 would spill: 384-pixel tiles only
-        conv3_run<CFG, 3>(p, bm.x >> 8, bm.y, nb, smem);
+        conv3_run<CFG, 3>(p, nt, bm.y, tiles, nb, smem);
     } else {
         if (p.bm == 512)
-            conv3_run<CFG, 4>(p, bm.x >> 8, bm.y, nb, smem);
+            conv3_run<CFG, 4>(p, nt, bm.y, tiles, nb, smem);
         else
-            conv3_run<CFG, 3>(p, bm.x >> 8, bm.y, nb, smem);  // bm == 384
+            conv3_run<CFG, 3>(p, nt, bm.y, tiles, nb, smem);  // bm == 384
     }
 }
 

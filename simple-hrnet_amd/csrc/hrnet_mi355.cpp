@@ -126,6 +126,8 @@ struct hrn_ctx {
     bool tap_stride2 = getenv("HRN_TAP_STRIDE2") != nullptr;  // stride-2 via the tap kernel (slower than direct so far)
     int half_stages_per_block = getenv("HRN_HALF_STAGES") ? atoi(getenv("HRN_HALF_STAGES")) : 8;
     int block_order = getenv("HRN_BLOCK_ORDER") ? atoi(getenv("HRN_BLOCK_ORDER")) : 1;
+    int long_factor = getenv("HRN_LONG_FACTOR") ? atoi(getenv("HRN_LONG_FACTOR")) : 4;
+    double long_share = getenv("HRN_LONG_SHARE") ? atof(getenv("HRN_LONG_SHARE")) : 0.85;
     int head_slabs = 1, head_slab_px = 1024;
     float *part_val = nullptr;
     int *part_idx = nullptr;
@@ -464,7 +466,7 @@ struct hrn_ctx {
     }
 
     // device-resident descriptors + block maps of the grouped conv launches
-    int group_blocks(const Conv3Group &g, int nb, std::vector<int2> *out) const {
+    int group_blocks(const Conv3Group &g, int nb, std::vector<int2> *out, bool all_short = false) const {
         struct Ent {
             double key;
             int2 v;
@@ -475,27 +477,36 @@ struct hrn_ctx {
             const Tensor &to = tensors[cv.out_t];
             const int bm = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
             const int mtiles = (nb * to.hpwp + bm - 1) / bm;
-            const int tpb = conv3_tiles_per_block(cv);
-            const int mgroups = (mtiles + tpb - 1) / tpb;
-            const int total = mgroups * cv.ntiles;
-            // XCD-aware order inside a problem: the hardware places block id b on XCD b % 8 (private L2 each).  Emit
-            // rounds of 8 M groups x all cout tiles with the M group varying fastest, so the cout tiles of one M group
-            // are 8 ids apart = on the same XCD, and re-read its slab from that L2 instead of over the fabric.
-            int seq = 0;
-            for (int round = 0; round * 8 < mgroups; ++round)
-                for (int nt = 0; nt < cv.ntiles; ++nt)
-                    for (int x = 0; x < 8; ++x) {
-                        const int mg = round * 8 + x;
-                        if (mg >= mgroups) continue;
-                        const int i = seq++;
-                        double key = (i + 0.5) / total;  // proportional interleave of the problems
-                        if (block_order == 1) {          // longest-processing-time first (estimated block cost)
-                            int tiles = mtiles - mg * tpb;
+            // Blocks come in two lengths: long ones (fewer pipeline prologues -- a block's first loads have nothing to
+            // hide behind) over the first `long_share` of the M tiles, short ones over the rest to fill the tail.
+            const int tpb_short = conv3_tiles_per_block(cv);
+            const int tpb_long = tpb_short * (all_short ? 1 : long_factor);
+            const int long_tiles = ((int)(mtiles * long_share) / (8 * tpb_long)) * (8 * tpb_long);  // whole XCD rounds
+            for (int phase = 0; phase < 2; ++phase) {
+                const int tpb = phase == 0 ? tpb_long : tpb_short;
+                const int first = phase == 0 ? 0 : long_tiles;
+                const int count = phase == 0 ? long_tiles : mtiles - long_tiles;
+                if (count <= 0) continue;
+                const int mgroups = (count + tpb - 1) / tpb;
+                const int total = mgroups * cv.ntiles;
+                // XCD-aware order inside a problem: the hardware places block id b on XCD b % 8 (private L2 each).
+                // Emit rounds of 8 M groups x all cout tiles with the M group varying fastest, so the cout tiles of one
+                // M group are 8 ids apart = on the same XCD, and re-read its slab from that L2, not over the fabric.
+                int seq = 0;
+                for (int round = 0; round * 8 < mgroups; ++round)
+                    for (int nt = 0; nt < cv.ntiles; ++nt)
+                        for (int x = 0; x < 8; ++x) {
+                            const int mg = round * 8 + x;
+                            if (mg >= mgroups) continue;
+                            const int i = seq++;
+                            int tiles = count - mg * tpb;
                             if (tiles > tpb) tiles = tpb;
-                            key = -(double)tiles * (cv.slices * 2.0 * (bm == 512 ? 4300.0 : 3500.0) + (bm == 512 ? 5000.0 : 3000.0)) + 1e-3 * key;
+                            double key = (i + 0.5) / total;  // proportional interleave of the problems
+                            if (block_order == 1)            // longest-processing-time first (estimated block cost)
+                                key = -(double)tiles * (cv.slices * 2.0 * (bm == 512 ? 4300.0 : 3500.0) + (bm == 512 ? 5000.0 : 3000.0)) + 1e-3 * key;
+                            ents.push_back({key, int2{(int)k | (nt << 8) | (tiles << 16), first + mg * tpb}});
                         }
-                        ents.push_back({key, int2{(int)k | (nt << 8), mg * tpb}});
-                    }
+            }
         }
         std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
         if (out) {
@@ -545,7 +556,7 @@ struct hrn_ctx {
                 fast_div(to.wp, &q.magic_wp, &q.shift_wp);
                 if (to.wp > g.max_wp) g.max_wp = to.wp;
             }
-            g.map_capacity = group_blocks(g, max_batch, nullptr);
+            g.map_capacity = group_blocks(g, max_batch, nullptr, true) + 64;  // all-short split = most blocks
             if (!hip_ok(hipMalloc((void **)&g.map_dev, (size_t)g.map_capacity * sizeof(int2)), "hipMalloc(blockmap)"))
                 return false;
             workspace_bytes += g.map_capacity * (int64_t)sizeof(int2);
