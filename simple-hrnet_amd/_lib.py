@@ -37,14 +37,26 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source of the package for gfx950 into ``libhrnet_mi355.so``."""
+    """Compile every HIP source of the package for gfx950 into ``libhrnet_mi355.so``.
+
+    Safe under concurrent callers (the N ranks of a torch.distributed launch all import the package): the build
+    runs under an exclusive file lock, into a per-process temporary, and is skipped by whoever arrives second."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    import fcntl
+
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or needs_build():
+                tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+                cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
