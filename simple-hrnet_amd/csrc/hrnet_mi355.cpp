@@ -37,7 +37,7 @@ struct Buffer {
     bool in_use = false;
 };
 
-enum OpKind { OP_STEM, OP_CONV, OP_CONV3_GROUP, OP_FUSE, OP_HEAD, OP_DECODE };
+enum OpKind { OP_STEM, OP_CONV, OP_CONV3_GROUP, OP_CONV_GROUP, OP_FUSE, OP_HEAD, OP_DECODE };
 
 struct ConvOp {
     std::string conv, bn;  // state_dict prefixes ("" bn => plain bias conv)
@@ -61,6 +61,19 @@ struct Conv3Group {
     int max_wp = 0;
     int64_t map_capacity = 0;    // blocks at max_batch
     int2 *map_dev = nullptr;
+    std::vector<int2> map_host;
+    int cached_nb = -1;
+    int nblocks = 0;
+};
+
+// a set of independent convolutions on the generic kernel issued as ONE launch (kernels.hip: conv_direct_group_kernel)
+struct DirectGroup {
+    std::vector<int> conv_idx;
+    int nr = 0;
+    ConvArgs *args_dev = nullptr;
+    int2 *map_dev = nullptr;
+    int64_t map_capacity = 0;
+    std::vector<ConvArgs> args_host;
     std::vector<int2> map_host;
     int cached_nb = -1;
     int nblocks = 0;
@@ -108,6 +121,7 @@ struct hrn_ctx {
     std::vector<ConvOp> convs;
     std::vector<FuseOp> fuses;
     std::vector<Conv3Group> groups;
+    std::vector<DirectGroup> dgroups;
     Conv3Problem *probs_dev = nullptr;
     std::vector<Op> ops;
     int stem_out_t = -1, head_in_t = -1;
@@ -120,6 +134,9 @@ struct hrn_ctx {
     bool disable_lds = getenv("HRN_DISABLE_LDS") != nullptr;
     bool disable_group = getenv("HRN_DISABLE_GROUP") != nullptr;
     bool disable_tap = getenv("HRN_DISABLE_TAP") != nullptr;
+    bool disable_dgroup = getenv("HRN_DISABLE_DGROUP") != nullptr;
+    // 1: convolutions that read the same tensor share one cout-tile width so that they can share a launch (and L2)
+    int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
     bool disable_stem_mfma = getenv("HRN_DISABLE_STEM_MFMA") != nullptr;
     bool direct_nr6 = getenv("HRN_DIRECT_NR6") ? atoi(getenv("HRN_DIRECT_NR6")) != 0 : true;
@@ -158,8 +175,21 @@ struct hrn_ctx {
     }
     void release(int t) { buffers[tensors[t].buf].in_use = false; }
 
+    int default_nr(int cout, int stride) const {
+        int nr = (cout % 64 == 0) ? 4 : (cout % 48 == 0) ? 3 : 2;
+        if (dtype == HRN_BF16 && stride == 2 && cout % 96 == 0 && direct_nr6) nr = 6;  // halves the A gathers per MFMA
+        return nr;
+    }
+    // widest cout tile every member of a set of sibling convolutions can use
+    int common_nr(const std::vector<int> &couts, int stride) const {
+        bool all64 = true, all48 = true, all96 = true;
+        for (int co : couts) all64 &= co % 64 == 0, all48 &= co % 48 == 0, all96 &= co % 96 == 0;
+        if (dtype == HRN_BF16 && stride == 2 && all96 && direct_nr6) return 6;
+        return all64 ? 4 : all48 ? 3 : 2;
+    }
+
     int add_conv(const std::string &conv, const std::string &bn, int in_t, int cout, int k, int stride, int relu,
-                 int res_t = -1, bool emit = true) {
+                 int res_t = -1, bool emit = true, int nr_override = 0) {
         const Tensor ti = tensors[in_t];  // by value: new_tensor() below may reallocate `tensors`
         ConvOp op;
         op.conv = conv, op.bn = bn, op.in_t = in_t, op.res_t = res_t;
@@ -170,8 +200,7 @@ struct hrn_ctx {
         const int K = k * k * op.cin;
         op.kchunks = (K + kc - 1) / kc;
         op.kpad = op.kchunks * kc;
-        op.nr = (cout % 64 == 0) ? 4 : (cout % 48 == 0) ? 3 : 2;
-        if (dtype == HRN_BF16 && stride == 2 && cout % 96 == 0 && direct_nr6) op.nr = 6;  // halves the A gathers per MFMA
+        op.nr = nr_override ? nr_override : default_nr(cout, stride);
         op.flops = 2.0 * cout * (double)K * oh * ow;
         // pipelined LDS kernel (conv3x3_lds.hip): KS = 48 / 48-cout tiles for the HRNet-W48 branch widths, KS = 32 with
         // 64-, 48- or 32-cout tiles for everything else whose channel counts are multiples of 32
@@ -258,11 +287,32 @@ struct hrn_ctx {
     // LDS-staged kernel, individual launches otherwise
     void emit_convs(const std::vector<int> &idx) {
         std::vector<int> lds;
+        std::vector<std::vector<int>> dsets;  // generic kernel: one launch per cout-tile width
         for (int i : idx) {
-            if (convs[i].algo == 1)
+            if (convs[i].algo == 1) {
                 lds.push_back(i);
-            else
+            } else if (convs[i].algo == 0 && !disable_dgroup) {
+                bool placed = false;
+                for (auto &set : dsets)
+                    if (convs[set[0]].nr == convs[i].nr && set.size() < 255) {
+                        set.push_back(i);
+                        placed = true;
+                        break;
+                    }
+                if (!placed) dsets.push_back({i});
+            } else {
                 ops.push_back({OP_CONV, i});
+            }
+        }
+        for (auto &set : dsets) {
+            if (set.size() == 1) {
+                ops.push_back({OP_CONV, set[0]});
+                continue;
+            }
+            DirectGroup g;
+            g.conv_idx = set, g.nr = convs[set[0]].nr;
+            dgroups.push_back(g);
+            ops.push_back({OP_CONV_GROUP, (int)dgroups.size() - 1});
         }
         if (lds.empty()) return;
         std::vector<std::vector<int>> sets;  // one launch per (KS, NRB) configuration
@@ -328,33 +378,57 @@ struct hrn_ctx {
             }
             emit_convs(g2);
         }
-        std::vector<int> outs;
-        for (int i = 0; i < nout; ++i) {
-            std::vector<int> terms, shifts, temps;
+        // fuse layers (hrnet.py:25-51, 60-69).  The convolutions feeding the sums are issued level by level -- level 0 =
+        // every 1x1 conv and the first conv of every stride-2 chain, level k = the k-th conv of the chains -- so that
+        // each level is a handful of grouped launches in which siblings reading the same branch share L2.
+        std::vector<std::vector<int>> term(nout, std::vector<int>(nb, -1));
+        std::vector<std::vector<int>> cur(nout, std::vector<int>(nb, -1));
+        for (int level = 0; level < nb; ++level) {
+            std::vector<int> made, dead;
             for (int j = 0; j < nb; ++j) {
-                snprintf(buf, sizeof buf, "%s.fuse_layers.%d.%d", name.c_str(), i, j);
-                const std::string q = buf;
-                if (i == j) {
-                    terms.push_back(xs[j]), shifts.push_back(0);
-                } else if (i < j) {  // 1x1 conv + BN, upsample folded into the fuse read (hrnet.py:30-35)
-                    const int lo = add_conv(q + ".0", q + ".1", xs[j], c << i, 1, 1, 0);
-                    terms.push_back(lo), shifts.push_back(j - i), temps.push_back(lo);
-                } else {  // chain of 3x3 s2 convs (hrnet.py:36-51)
-                    int t = xs[j];
-                    for (int k = 0; k < i - j; ++k) {
-                        const bool last = (k == i - j - 1);
-                        snprintf(buf, sizeof buf, "%s.%d", q.c_str(), k);
+                std::vector<int> c1, c2;  // couts of the level's 1x1 / stride-2 readers of branch j
+                if (level == 0)
+                    for (int i = 0; i < nout && i < j; ++i) c1.push_back(c << i);
+                for (int i = j + 1 + level; i < nout; ++i)
+                    if (level == 0) c2.push_back(i - j == 1 ? (c << i) : (c << j));
+                const int nr1 = (dgroup_nr_mode == 1 && c1.size() > 1) ? common_nr(c1, 1) : 0;
+                const int nr2 = (dgroup_nr_mode == 1 && c2.size() > 1) ? common_nr(c2, 2) : 0;
+                for (int i = 0; i < nout; ++i) {
+                    snprintf(buf, sizeof buf, "%s.fuse_layers.%d.%d", name.c_str(), i, j);
+                    const std::string q = buf;
+                    if (i < j && level == 0) {  // 1x1 conv + BN, upsample folded into the fuse read (hrnet.py:30-35)
+                        term[i][j] = add_conv(q + ".0", q + ".1", xs[j], c << i, 1, 1, 0, -1, false, nr1);
+                        made.push_back((int)convs.size() - 1);
+                    } else if (i > j && level < i - j) {  // chain of 3x3 s2 convs (hrnet.py:36-51)
+                        const bool last = (level == i - j - 1);
+                        snprintf(buf, sizeof buf, "%s.%d", q.c_str(), level);
                         const std::string qq = buf;
-                        const int nt = add_conv(qq + ".0", qq + ".1", t, last ? (c << i) : (c << j), 3, 2, last ? 0 : 1);
-                        if (t != xs[j]) release(t);
-                        t = nt;
+                        const int src = level == 0 ? xs[j] : cur[i][j];
+                        const int nt = add_conv(qq + ".0", qq + ".1", src, last ? (c << i) : (c << j), 3, 2, last ? 0 : 1, -1,
+                                                false, level == 0 ? nr2 : 0);
+                        made.push_back((int)convs.size() - 1);
+                        if (level > 0) dead.push_back(src);
+                        cur[i][j] = nt;
+                        if (last) term[i][j] = nt;
                     }
-                    terms.push_back(t), shifts.push_back(0), temps.push_back(t);
                 }
             }
-            outs.push_back(add_fuse(terms, shifts));
-            for (int t : temps) release(t);
+            if (made.empty()) break;
+            emit_convs(made);
+            for (int t : dead) release(t);  // only now: members of one launch must not recycle each other's inputs
         }
+        std::vector<int> outs;
+        for (int i = 0; i < nout; ++i) {
+            std::vector<int> terms, shifts;
+            for (int j = 0; j < nb; ++j) {
+                terms.push_back(i == j ? xs[j] : term[i][j]);
+                shifts.push_back(i < j ? j - i : 0);
+            }
+            outs.push_back(add_fuse(terms, shifts));
+        }
+        for (int i = 0; i < nout; ++i)
+            for (int j = 0; j < nb; ++j)
+                if (i != j) release(term[i][j]);
         for (int b = 0; b < nb; ++b) release(xs[b]);
         xs = outs;
     }
@@ -371,10 +445,16 @@ struct hrn_ctx {
         for (int b = 0; b < 4; ++b) {  // layer1: Bottleneck x4, modules.py:20-40
             snprintf(buf, sizeof buf, "layer1.%d", b);
             const std::string p = buf;
-            const int o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1);
-            const int o2 = add_conv(p + ".conv2", p + ".bn2", o1, 64, 3, 1, 1);
+            std::vector<int> first;  // conv1 and the projection shortcut both read x: one launch
+            const int o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1, -1, false);
+            first.push_back((int)convs.size() - 1);
             int r = x;
-            if (b == 0) r = add_conv(p + ".downsample.0", p + ".downsample.1", x, 256, 1, 1, 0);
+            if (b == 0) {
+                r = add_conv(p + ".downsample.0", p + ".downsample.1", x, 256, 1, 1, 0, -1, false);
+                first.push_back((int)convs.size() - 1);
+            }
+            emit_convs(first);
+            const int o2 = add_conv(p + ".conv2", p + ".bn2", o1, 64, 3, 1, 1);
             const int o3 = add_conv(p + ".conv3", p + ".bn3", o2, 256, 1, 1, 1, r);
             release(o1), release(o2);
             if (b == 0) release(r);
@@ -382,8 +462,9 @@ struct hrn_ctx {
             x = o3;
         }
         std::vector<int> xs;
-        xs.push_back(add_conv("transition1.0.0", "transition1.0.1", x, c, 3, 1, 1));
-        xs.push_back(add_conv("transition1.1.0.0", "transition1.1.0.1", x, 2 * c, 3, 2, 1));
+        xs.push_back(add_conv("transition1.0.0", "transition1.0.1", x, c, 3, 1, 1, -1, false));
+        xs.push_back(add_conv("transition1.1.0.0", "transition1.1.0.1", x, 2 * c, 3, 2, 1, -1, false));
+        emit_convs({(int)convs.size() - 2, (int)convs.size() - 1});
         release(x);
         add_stage("stage2.0", xs, 2);
         xs.push_back(add_conv("transition2.2.0.0", "transition2.2.0.1", xs[1], 4 * c, 3, 2, 1));
@@ -453,7 +534,7 @@ struct hrn_ctx {
         }
         if (!hip_ok(hipMalloc((void **)&blob, (size_t)blob_bytes), "hipMalloc(weights)")) return false;
         if (!hip_ok(hipMemset(blob, 0, (size_t)blob_bytes), "hipMemset(weights)")) return false;
-        if (!setup_groups() || !setup_tap_tables()) return false;
+        if (!setup_groups() || !setup_dgroups() || !setup_tap_tables()) return false;
         if (!hip_ok(hipMalloc((void **)&part_val, (size_t)part * 4), "hipMalloc(part_val)")) return false;
         if (!hip_ok(hipMalloc((void **)&part_idx, (size_t)part * 4), "hipMalloc(part_idx)")) return false;
         return hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
@@ -472,6 +553,24 @@ struct hrn_ctx {
             int2 v;
         };
         std::vector<Ent> ents;
+        // Block lengths follow the size of the launch: small batches get shorter blocks (at least ~2 per CU before
+        // anything else), and long blocks are only worth it when there are many blocks per CU to begin with.
+        auto count_blocks = [&](int div) {
+            long total = 0;
+            for (int ci : g.conv_idx) {
+                const ConvOp &cv = convs[ci];
+                const Tensor &to = tensors[cv.out_t];
+                const int bm = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+                const int mtiles = (nb * to.hpwp + bm - 1) / bm;
+                const int tpb = std::max(1, conv3_tiles_per_block(cv) / div);
+                total += (long)((mtiles + tpb - 1) / tpb) * cv.ntiles;
+            }
+            return total;
+        };
+        int div = 1;
+        while (div < 64 && count_blocks(div) < 512) div *= 2;
+        int lf = all_short ? 1 : (int)std::min<long>(long_factor, count_blocks(div) / 768);
+        if (lf < 1) lf = 1;
         for (size_t k = 0; k < g.conv_idx.size(); ++k) {
             const ConvOp &cv = convs[g.conv_idx[k]];
             const Tensor &to = tensors[cv.out_t];
@@ -479,8 +578,8 @@ struct hrn_ctx {
             const int mtiles = (nb * to.hpwp + bm - 1) / bm;
             // Blocks come in two lengths: long ones (fewer pipeline prologues -- a block's first loads have nothing to
             // hide behind) over the first `long_share` of the M tiles, short ones over the rest to fill the tail.
-            const int tpb_short = conv3_tiles_per_block(cv);
-            const int tpb_long = tpb_short * (all_short ? 1 : long_factor);
+            const int tpb_short = std::max(1, conv3_tiles_per_block(cv) / div);
+            const int tpb_long = tpb_short * lf;
             const int long_tiles = ((int)(mtiles * long_share) / (8 * tpb_long)) * (8 * tpb_long);  // whole XCD rounds
             for (int phase = 0; phase < 2; ++phase) {
                 const int tpb = phase == 0 ? tpb_long : tpb_short;
@@ -514,6 +613,69 @@ struct hrn_ctx {
             for (size_t i = 0; i < ents.size(); ++i) (*out)[i] = ents[i].v;
         }
         return (int)ents.size();
+    }
+
+    ConvArgs conv_args(const ConvOp &cv, int nb) const {
+        const Tensor &ti = tensors[cv.in_t], &to = tensors[cv.out_t];
+        ConvArgs a;
+        a.in = row0(cv.in_t), a.out = row0(cv.out_t);
+        a.w = blob + cv.w_off, a.bias = (const float *)(blob + cv.b_off);
+        a.res = cv.res_t >= 0 ? row0(cv.res_t) : nullptr;
+        a.cin = cv.cin, a.cout = cv.cout;
+        a.in_wp = ti.wp, a.in_hpwp = ti.hpwp;
+        a.out_h = to.h, a.out_w = to.w, a.out_wp = to.wp, a.out_hpwp = to.hpwp;
+        a.m = nb * to.hpwp;
+        a.ksize = cv.k, a.stride = cv.stride, a.relu = cv.relu, a.kchunks = cv.kchunks;
+        return a;
+    }
+
+    // Block map of a grouped launch of the generic kernel.  Convolutions that read the same tensor with the same
+    // window form a class; inside a class the map walks rounds of 8 M tiles and, per round, every (conv, cout tile)
+    // of the class with the M tile varying fastest: block id b runs on XCD b % 8, so all readers of one input tile
+    // are 8 ids apart = on one XCD, back to back, and the tile comes from HBM once.  Rounds are padded to 8 entries
+    // (an out-of-range M tile returns at once) to keep that alignment.  Classes go out costliest first.
+    int direct_group_blocks(const DirectGroup &g, int nb, std::vector<int2> *out) const {
+        struct Cls {
+            int in_t, k, stride;
+            std::vector<int> members;
+            double cost = 0;
+        };
+        std::vector<Cls> cls;
+        for (size_t k = 0; k < g.conv_idx.size(); ++k) {
+            const ConvOp &cv = convs[g.conv_idx[k]];
+            size_t ci = 0;
+            for (; ci < cls.size(); ++ci)
+                if (cls[ci].in_t == cv.in_t && cls[ci].k == cv.k && cls[ci].stride == cv.stride) break;
+            if (ci == cls.size()) cls.push_back(Cls{cv.in_t, cv.k, cv.stride, {}, 0});
+            cls[ci].members.push_back((int)k);
+            cls[ci].cost += (double)tensors[cv.out_t].hpwp * (cv.cout / (16 * g.nr)) * cv.kchunks;
+        }
+        std::stable_sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.cost > b.cost; });
+        int n = 0;
+        if (out) out->clear();
+        for (const Cls &cl : cls) {
+            const int mtiles = (nb * tensors[convs[g.conv_idx[cl.members[0]]].out_t].hpwp + 255) / 256;
+            for (int round = 0; round * 8 < mtiles; ++round)
+                for (int k : cl.members) {
+                    const int ngroups = convs[g.conv_idx[k]].cout / (16 * g.nr);
+                    for (int ng = 0; ng < ngroups; ++ng)
+                        for (int x = 0; x < 8; ++x, ++n)
+                            if (out) out->push_back(int2{k | (ng << 8), round * 8 + x});
+                }
+        }
+        return n;
+    }
+
+    bool setup_dgroups() {
+        for (auto &g : dgroups) {
+            g.map_capacity = direct_group_blocks(g, max_batch, nullptr);
+            if (!hip_ok(hipMalloc((void **)&g.map_dev, (size_t)g.map_capacity * sizeof(int2)), "hipMalloc(blockmap)"))
+                return false;
+            if (!hip_ok(hipMalloc((void **)&g.args_dev, g.conv_idx.size() * sizeof(ConvArgs)), "hipMalloc(conv args)"))
+                return false;
+            workspace_bytes += g.map_capacity * (int64_t)sizeof(int2) + (int64_t)(g.conv_idx.size() * sizeof(ConvArgs));
+        }
+        return true;
     }
 
     bool setup_tap_tables() {
@@ -556,7 +718,13 @@ struct hrn_ctx {
                 fast_div(to.wp, &q.magic_wp, &q.shift_wp);
                 if (to.wp > g.max_wp) g.max_wp = to.wp;
             }
-            g.map_capacity = group_blocks(g, max_batch, nullptr, true) + 64;  // all-short split = most blocks
+            g.map_capacity = 64;  // one M tile per block = most blocks any split can produce
+            for (int ci : g.conv_idx) {
+                const ConvOp &cv = convs[ci];
+                const Tensor &to = tensors[cv.out_t];
+                const int bm = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+                g.map_capacity += (int64_t)((max_batch * to.hpwp + bm - 1) / bm) * cv.ntiles;
+            }
             if (!hip_ok(hipMalloc((void **)&g.map_dev, (size_t)g.map_capacity * sizeof(int2)), "hipMalloc(blockmap)"))
                 return false;
             workspace_bytes += g.map_capacity * (int64_t)sizeof(int2);
@@ -581,6 +749,10 @@ struct hrn_ctx {
                 if (cv.tap_dev) (void)hipFree(cv.tap_dev);
             for (auto &g : groups)
                 if (g.map_dev) (void)hipFree(g.map_dev);
+            for (auto &g : dgroups) {
+                if (g.map_dev) (void)hipFree(g.map_dev);
+                if (g.args_dev) (void)hipFree(g.args_dev);
+            }
         }
         blob = nullptr;
     }
@@ -805,7 +977,7 @@ struct hrn_ctx {
                 }
                 case OP_CONV: {
                     const ConvOp &cv = convs[op.idx];
-                    const Tensor &ti = tensors[cv.in_t], &to = tensors[cv.out_t];
+                    const Tensor &to = tensors[cv.out_t];
                     if (cv.algo == 2) {
                         TapConvArgs a;
                         a.out = row0(cv.out_t), a.bias = (const float *)(blob + cv.b_off);
@@ -822,15 +994,7 @@ struct hrn_ctx {
                         e = launch_conv_tap_lds(a, cv.ks, cv.nr, s);
                         break;
                     }
-                    ConvArgs a;
-                    a.in = row0(cv.in_t), a.out = row0(cv.out_t);
-                    a.w = blob + cv.w_off, a.bias = (const float *)(blob + cv.b_off);
-                    a.res = cv.res_t >= 0 ? row0(cv.res_t) : nullptr;
-                    a.cin = cv.cin, a.cout = cv.cout;
-                    a.in_wp = ti.wp, a.in_hpwp = ti.hpwp;
-                    a.out_h = to.h, a.out_w = to.w, a.out_wp = to.wp, a.out_hpwp = to.hpwp;
-                    a.m = nb * to.hpwp;
-                    a.ksize = cv.k, a.stride = cv.stride, a.relu = cv.relu, a.kchunks = cv.kchunks;
+                    const ConvArgs a = conv_args(cv, nb);
                     e = launch_conv(dtype, a, cv.nr, s);
                     break;
                 }
@@ -845,6 +1009,23 @@ struct hrn_ctx {
                     }
                     e = launch_conv3x3_lds(probs_dev + g.prob_first, g.map_dev, g.nblocks, nb, convs[g.conv_idx[0]].ks,
                                            convs[g.conv_idx[0]].nr, s);
+                    break;
+                }
+                case OP_CONV_GROUP: {
+                    DirectGroup &g = dgroups[op.idx];
+                    if (g.cached_nb != nb) {  // descriptors (row counts) and block map depend on the micro-batch size
+                        g.args_host.clear();
+                        for (int ci : g.conv_idx) g.args_host.push_back(conv_args(convs[ci], nb));
+                        g.nblocks = direct_group_blocks(g, nb, &g.map_host);
+                        e = hipMemcpyAsync(g.args_dev, g.args_host.data(), g.args_host.size() * sizeof(ConvArgs),
+                                           hipMemcpyHostToDevice, s);
+                        if (e != hipSuccess) break;
+                        e = hipMemcpyAsync(g.map_dev, g.map_host.data(), (size_t)g.nblocks * sizeof(int2),
+                                           hipMemcpyHostToDevice, s);
+                        if (e != hipSuccess) break;
+                        g.cached_nb = nb;
+                    }
+                    e = launch_conv_group(dtype, g.args_dev, g.map_dev, g.nblocks, g.nr, s);
                     break;
                 }
                 case OP_FUSE: {
@@ -1072,6 +1253,17 @@ int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms
                 for (int ci : g.conv_idx) tot += h->convs[ci].flops;
                 for (int ci : g.conv_idx)
                     if (conv_ms && ci < conv_ms_len) conv_ms[ci] = (float)(ms * h->convs[ci].flops / tot);
+            } else if (op.kind == OP_CONV_GROUP) {  // likewise; these are latency / bandwidth bound: split by block count
+                const DirectGroup &g = h->dgroups[op.idx];
+                double tot = 0;
+                std::vector<double> wgt;
+                for (int ci : g.conv_idx) {
+                    const ConvOp &cv = h->convs[ci];
+                    wgt.push_back((double)h->tensors[cv.out_t].hpwp * (cv.cout / (16 * g.nr)) * cv.kchunks);
+                    tot += wgt.back();
+                }
+                for (size_t k = 0; k < g.conv_idx.size(); ++k)
+                    if (conv_ms && g.conv_idx[k] < conv_ms_len) conv_ms[g.conv_idx[k]] = (float)(ms * wgt[k] / tot);
             } else if (other_ms) {
                 const int slot = op.kind == OP_STEM ? 0 : op.kind == OP_FUSE ? 1 : op.kind == OP_HEAD ? 2 : 3;
                 other_ms[slot] += ms;

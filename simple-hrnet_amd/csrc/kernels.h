@@ -122,6 +122,9 @@ struct DecodeArgs {        // SimpleHRNet.py:297-308
 };
 
 hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s);
+// grouped launch of the generic kernel: device-resident ConvArgs[], block map entries (prob | cout tile << 8, M tile)
+hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr,
+                             hipStream_t s);
 hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb, int ks,
                               int nrb, hipStream_t s);
 hipError_t launch_stem(int dtype, const StemArgs &a, hipStream_t s);

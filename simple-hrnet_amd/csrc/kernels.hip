@@ -66,22 +66,21 @@ __device__ __forceinline__ f32x4 mma<DT_F32>(f32x4 w, f32x4 x, f32x4 acc) {
 //   lane (li = lane&15, g = lane>>4):  X operand = pixel li, k-group g (VEC consecutive ci of one tap);
 //   W operand = packed row li, k-group g (pre-packed so the load is lane-linear: lane*16 B).
 //   result: lane holds pixel li, channels ch0 + [0, 4*NR), ch0 = ng*16*NR + g*4*NR  (see pack_conv_weights).
+#define GLOBAL_AS __attribute__((address_space(1)))
+
 template <int DT, int NR, int MR>
-__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
+__device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng, const int mtile) {
     using T = Tr<DT>;
     using vec = typename T::vec;
     using elem = typename T::elem;
+    typedef const GLOBAL_AS vec *gvec_p;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
-    // 1-D grid, cout tile fastest: the blocks that share an activation tile are dispatched together, so the
-    // tile is fetched from HBM once and re-read from L2
-    // the hardware places block b on XCD b % 8 (private L2s): the cout tiles of one M tile are issued 8 ids apart
-    const int ngroups = p.cout / (16 * NR);
-    const int ng = (blockIdx.x >> 3) % ngroups;
-    const int mtile = (blockIdx.x / (8 * ngroups)) * 8 + (blockIdx.x & 7);
     const int m0 = (mtile * 4 + wave) * (16 * MR);
     if (mtile * 64 * MR >= p.m) return;
-    const elem *__restrict__ in = (const elem *)p.in;
+    // descriptor pointers may have come from memory (grouped launch): name the address space, or every access
+    // through them is a FLAT one
+    const GLOBAL_AS elem *__restrict__ in = (const GLOBAL_AS elem *)p.in;
 
     long inrow[MR];
 #pragma unroll
@@ -112,12 +111,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
         ++tap;
     }
     const int ntaps = p.ksize * p.ksize;
-    const char *__restrict__ wlane = (const char *)p.w + ((size_t)ng * NR * p.kchunks * 64 + lane) * 16;
+    const GLOBAL_AS char *__restrict__ wlane =
+        (const GLOBAL_AS char *)p.w + ((size_t)ng * NR * p.kchunks * 64 + lane) * 16;
 
     for (int kc = 0; kc < p.kchunks; ++kc) {
         vec b[NR];
 #pragma unroll
-        for (int j = 0; j < NR; ++j) b[j] = *(const vec *)(wlane + ((size_t)j * p.kchunks + kc) * 1024);
+        for (int j = 0; j < NR; ++j) b[j] = *(gvec_p)(wlane + ((size_t)j * p.kchunks + kc) * 1024);
         vec a[MR];
         if (tap < ntaps) {
             int tapoff = 0;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
             }
             const long aoff = (long)tapoff * p.cin + ci;
 #pragma unroll
-            for (int i = 0; i < MR; ++i) a[i] = *(const vec *)(in + inrow[i] + aoff);
+            for (int i = 0; i < MR; ++i) a[i] = *(gvec_p)(in + inrow[i] + aoff);
         } else {  // K padding: weights are zero there, feed zeros
 #pragma unroll
             for (int i = 0; i < MR; ++i) a[i] = vec{};
@@ -147,9 +147,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
     const int ch0 = ng * 16 * NR + g * 4 * NR;
     float bias[4 * NR];
 #pragma unroll
-    for (int c = 0; c < 4 * NR; ++c) bias[c] = p.bias[ch0 + c];
-    elem *__restrict__ out = (elem *)p.out;
-    const elem *__restrict__ res = (const elem *)p.res;
+    for (int c = 0; c < 4 * NR; ++c) bias[c] = ((const GLOBAL_AS float *)p.bias)[ch0 + c];
+    GLOBAL_AS elem *__restrict__ out = (GLOBAL_AS elem *)p.out;
+    const GLOBAL_AS elem *__restrict__ res = (const GLOBAL_AS elem *)p.res;
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
         const int q = m0 + i * 16 + li;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
 #pragma unroll
             for (int j = 0; j < NR; j += 2) {
                 s16x8 r8 = {};
-                if (res) r8 = *(const s16x8 *)(res + o + j * 4);
+                if (res) r8 = *(const GLOBAL_AS s16x8 *)(res + o + j * 4);
                 s16x8 o8;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -173,13 +173,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
                     if (!ok) v = 0.f;
                     o8[r] = (short)T::st(v);
                 }
-                *(s16x8 *)(out + o + j * 4) = o8;
+                *(GLOBAL_AS s16x8 *)(out + o + j * 4) = o8;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 typename T::out4 r4 = {};
-                if (res) r4 = *(const typename T::out4 *)(res + o + j * 4);
+                if (res) r4 = *(const GLOBAL_AS typename T::out4 *)(res + o + j * 4);
                 typename T::out4 o4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -189,10 +189,57 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
                     if (!ok) v = 0.f;
                     o4[r] = T::st(v);
                 }
-                *(typename T::out4 *)(out + o + j * 4) = o4;
+                *(GLOBAL_AS typename T::out4 *)(out + o + j * 4) = o4;
             }
         }
     }
+}
+
+// one convolution per launch.  1-D grid, cout tile fastest: the blocks that share an activation tile are dispatched
+// together, so the tile is fetched from HBM once and re-read from L2.  The hardware places block b on XCD b % 8
+// (private L2s): the cout tiles of one M tile are issued 8 ids apart.
+template <int DT, int NR, int MR>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
+    const int ngroups = p.cout / (16 * NR);
+    const int ng = (blockIdx.x >> 3) % ngroups;
+    const int mtile = (blockIdx.x / (8 * ngroups)) * 8 + (blockIdx.x & 7);
+    conv_direct_body<DT, NR, MR>(p, ng, mtile);
+}
+
+// several independent convolutions per launch: block b runs map[b] = (problem | cout tile << 8, M tile) of the
+// device-resident descriptor array (the host orders the map so that convolutions reading the same tensor sit on
+// the same XCD at the same time, hrnet_mi355.cpp: direct_group_blocks)
+template <int DT, int NR, int MR>
+__global__ __launch_bounds__(256) void conv_direct_group_kernel(const ConvArgs *__restrict__ probs,
+                                                                const int2 *__restrict__ map) {
+    const int2 e = map[blockIdx.x];
+    const int prob = __builtin_amdgcn_readfirstlane(e.x & 255), ng = __builtin_amdgcn_readfirstlane(e.x >> 8);
+    const int mtile = __builtin_amdgcn_readfirstlane(e.y);
+    const ConvArgs p = probs[prob];
+    conv_direct_body<DT, NR, MR>(p, ng, mtile);
+}
+
+template <int DT, int NR>
+static hipError_t launch_conv_group_t(const ConvArgs *probs, const int2 *map, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 4>), dim3(nblocks), dim3(256), 0, s, probs, map);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr,
+                             hipStream_t s) {
+    if (nblocks <= 0) return hipSuccess;
+    const int2 *map = (const int2 *)map_dev;
+    if (dtype == DT_BF16) {
+        if (nr == 6) return launch_conv_group_t<DT_BF16, 6>(probs_dev, map, nblocks, s);
+        if (nr == 4) return launch_conv_group_t<DT_BF16, 4>(probs_dev, map, nblocks, s);
+        if (nr == 3) return launch_conv_group_t<DT_BF16, 3>(probs_dev, map, nblocks, s);
+        if (nr == 2) return launch_conv_group_t<DT_BF16, 2>(probs_dev, map, nblocks, s);
+    } else {
+        if (nr == 4) return launch_conv_group_t<DT_F32, 4>(probs_dev, map, nblocks, s);
+        if (nr == 3) return launch_conv_group_t<DT_F32, 3>(probs_dev, map, nblocks, s);
+        if (nr == 2) return launch_conv_group_t<DT_F32, 2>(probs_dev, map, nblocks, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int DT, int NR>
