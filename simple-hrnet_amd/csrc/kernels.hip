@@ -10,6 +10,7 @@
 //   head_kernel         final 1x1 conv + bias, optional heat-map write-out, per-slab arg-max.
 //   decode_kernel       arg-max merge (first maximum wins) + box scaling in fp64, SimpleHRNet.py:297-308.
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace hrn {
 
@@ -68,7 +69,10 @@ __device__ __forceinline__ f32x4 mma<DT_F32>(f32x4 w, f32x4 x, f32x4 acc) {
 //   result: lane holds pixel li, channels ch0 + [0, 4*NR), ch0 = ng*16*NR + g*4*NR  (see pack_conv_weights).
 #define GLOBAL_AS __attribute__((address_space(1)))
 
-template <int DT, int NR, int MR>
+// PRE: the residual is fetched before the K loop instead of after it.  The 1x1 convs of layer1 have K = 64: the
+// loop is two chunks long and the kernel is a chain of memory round trips (operands, residual, store); this folds
+// the first two into one.  bf16, even NR only.
+template <int DT, int NR, int MR, bool PRE = false>
 __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng, const int mtile) {
     using T = Tr<DT>;
     using vec = typename T::vec;
@@ -104,6 +108,17 @@ __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng
     for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    s16x8 rpre[PRE ? MR : 1][PRE ? NR / 2 : 1];
+    if constexpr (PRE) {
+        const GLOBAL_AS elem *__restrict__ res = (const GLOBAL_AS elem *)p.res;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; j += 2)
+                rpre[i][j / 2] = *(const GLOBAL_AS s16x8 *)(res + (size_t)(m0 + i * 16 + li) * p.cout +
+                                                            ng * 16 * NR + g * 4 * NR + j * 4);
+    }
 
     int ci = g * T::VEC, tap = 0;
     while (ci >= p.cin) {
@@ -163,12 +178,15 @@ __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng
 #pragma unroll
             for (int j = 0; j < NR; j += 2) {
                 s16x8 r8 = {};
-                if (res) r8 = *(const GLOBAL_AS s16x8 *)(res + o + j * 4);
+                if constexpr (PRE)
+                    r8 = rpre[i][j / 2];
+                else if (res)
+                    r8 = *(const GLOBAL_AS s16x8 *)(res + o + j * 4);
                 s16x8 o8;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     float v = acc[i][j + (r >> 2)][r & 3] + bias[j * 4 + r];
-                    if (res) v += T::ld((elem)r8[r]);
+                    if (PRE || res) v += T::ld((elem)r8[r]);
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (!ok) v = 0.f;
                     o8[r] = (short)T::st(v);
@@ -198,12 +216,12 @@ __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng
 // one convolution per launch.  1-D grid, cout tile fastest: the blocks that share an activation tile are dispatched
 // together, so the tile is fetched from HBM once and re-read from L2.  The hardware places block b on XCD b % 8
 // (private L2s): the cout tiles of one M tile are issued 8 ids apart.
-template <int DT, int NR, int MR>
+template <int DT, int NR, int MR, bool PRE>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
     const int ngroups = p.cout / (16 * NR);
     const int ng = (blockIdx.x >> 3) % ngroups;
     const int mtile = (blockIdx.x / (8 * ngroups)) * 8 + (blockIdx.x & 7);
-    conv_direct_body<DT, NR, MR>(p, ng, mtile);
+    conv_direct_body<DT, NR, MR, PRE>(p, ng, mtile);
 }
 
 // several independent convolutions per launch: block b runs map[b] = (problem | cout tile << 8, M tile) of the
@@ -242,13 +260,23 @@ hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *m
     return hipErrorInvalidValue;
 }
 
-template <int DT, int NR>
-static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
-    constexpr int MR = 4;
+template <int DT, int NR, int MR, bool PRE>
+static hipError_t launch_conv_tt(const ConvArgs &a, hipStream_t s) {
     const int mtiles = (a.m + 64 * MR - 1) / (64 * MR);
     dim3 grid(((mtiles + 7) / 8) * 8 * (a.cout / (16 * NR)));
-    hipLaunchKernelGGL((conv_direct_kernel<DT, NR, MR>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_direct_kernel<DT, NR, MR, PRE>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+template <int DT, int NR>
+static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
+    if constexpr (DT == DT_BF16 && NR % 2 == 0) {
+        static const int pre_mode = getenv("HRN_PRE_MODE") ? atoi(getenv("HRN_PRE_MODE")) : 1;
+        if (a.res && a.ksize == 1 && pre_mode == 1) return launch_conv_tt<DT, NR, 4, true>(a, s);
+        if (a.res && a.ksize == 1 && pre_mode == 2) return launch_conv_tt<DT, NR, 2, true>(a, s);
+        if (a.res && a.ksize == 1 && pre_mode == 3) return launch_conv_tt<DT, NR, 2, false>(a, s);
+    }
+    return launch_conv_tt<DT, NR, 4, false>(a, s);
 }
 
 hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s) {
