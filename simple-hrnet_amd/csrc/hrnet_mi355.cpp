@@ -125,7 +125,7 @@ struct hrn_ctx {
     Conv3Problem *probs_dev = nullptr;
     std::vector<Op> ops;
     int stem_out_t = -1, head_in_t = -1;
-    int64_t stem_w_off = 0, stem_b_off = 0, stem_wp_off = 0, head_w_off = 0, head_b_off = 0;
+    int64_t stem_w_off = 0, stem_b_off = 0, stem_wp_off = 0, head_w_off = 0, head_b_off = 0, head_wp_off = 0;
 
     int64_t blob_bytes = 0;
     char *blob = nullptr;  // device (or host when plan_only)
@@ -139,9 +139,11 @@ struct hrn_ctx {
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
     bool disable_stem_mfma = getenv("HRN_DISABLE_STEM_MFMA") != nullptr;
+    bool disable_head_mfma = getenv("HRN_DISABLE_HEAD_MFMA") != nullptr;
     bool direct_nr6 = getenv("HRN_DIRECT_NR6") ? atoi(getenv("HRN_DIRECT_NR6")) != 0 : true;
     bool tap_stride2 = getenv("HRN_TAP_STRIDE2") != nullptr;  // stride-2 via the tap kernel (slower than direct so far)
     int half_stages_per_block = getenv("HRN_HALF_STAGES") ? atoi(getenv("HRN_HALF_STAGES")) : 8;
+    bool alternate = getenv("HRN_ALTERNATE") ? atoi(getenv("HRN_ALTERNATE")) != 0 : true;
     int block_order = getenv("HRN_BLOCK_ORDER") ? atoi(getenv("HRN_BLOCK_ORDER")) : 1;
     int long_factor = getenv("HRN_LONG_FACTOR") ? atoi(getenv("HRN_LONG_FACTOR")) : 4;
     double long_share = getenv("HRN_LONG_SHARE") ? atof(getenv("HRN_LONG_SHARE")) : 0.85;
@@ -504,6 +506,7 @@ struct hrn_ctx {
         }
         head_w_off = off, off = align_up(off + (int64_t)joints * c * 4, 256);
         head_b_off = off, off = align_up(off + joints * 4, 256);
+        head_wp_off = off, off = align_up(off + 2 * ((c + 31) / 32) * 1024, 256);  // bf16 MFMA image (head_mfma_kernel)
         blob_bytes = off;
 
         const int hw = (H / 4) * (W / 4);
@@ -547,7 +550,7 @@ struct hrn_ctx {
     }
 
     // device-resident descriptors + block maps of the grouped conv launches
-    int group_blocks(const Conv3Group &g, int nb, std::vector<int2> *out, bool all_short = false) const {
+    int group_blocks(const Conv3Group &g, int nb, std::vector<int2> *out, bool reverse, bool all_short = false) const {
         struct Ent {
             double key;
             int2 v;
@@ -603,7 +606,11 @@ struct hrn_ctx {
                             double key = (i + 0.5) / total;  // proportional interleave of the problems
                             if (block_order == 1)            // longest-processing-time first (estimated block cost)
                                 key = -(double)tiles * (cv.slices * 2.0 * (bm == 512 ? 4300.0 : 3500.0) + (bm == 512 ? 5000.0 : 3000.0)) + 1e-3 * key;
-                            ents.push_back({key, int2{(int)k | (nt << 8) | (tiles << 16), first + mg * tpb}});
+                            int mt0 = first + mg * tpb;
+                            // every other launch walks the tensors backwards: a launch starts on what its producer
+                            // wrote last, i.e. on the part most likely still in the Infinity Cache
+                            if (reverse) mt0 = mtiles - mt0 - tiles;
+                            ents.push_back({key, int2{(int)k | (nt << 8) | (tiles << 16), mt0}});
                         }
             }
         }
@@ -615,7 +622,7 @@ struct hrn_ctx {
         return (int)ents.size();
     }
 
-    ConvArgs conv_args(const ConvOp &cv, int nb) const {
+    ConvArgs conv_args(const ConvOp &cv, int nb, bool rev) const {
         const Tensor &ti = tensors[cv.in_t], &to = tensors[cv.out_t];
         ConvArgs a;
         a.in = row0(cv.in_t), a.out = row0(cv.out_t);
@@ -626,6 +633,7 @@ struct hrn_ctx {
         a.out_h = to.h, a.out_w = to.w, a.out_wp = to.wp, a.out_hpwp = to.hpwp;
         a.m = nb * to.hpwp;
         a.ksize = cv.k, a.stride = cv.stride, a.relu = cv.relu, a.kchunks = cv.kchunks;
+        a.rev = rev;
         return a;
     }
 
@@ -860,6 +868,17 @@ struct hrn_ctx {
                 return false;
             memcpy(host.data() + head_w_off, w, sizeof(float) * joints * c);
             memcpy(host.data() + head_b_off, b, sizeof(float) * joints);
+            // MFMA image: fragment f, chunk kc, lane (li, g): joint f*16 + li, k = kc*32 + g*8 + e
+            const int kch = (c + 31) / 32;
+            uint16_t *img = (uint16_t *)(host.data() + head_wp_off);
+            for (int f = 0; f < 2; ++f)
+                for (int kc = 0; kc < kch; ++kc)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int j = f * 16 + (lane & 15), k = kc * 32 + (lane >> 4) * 8 + e;
+                            img[((size_t)(f * kch + kc) * 64 + lane) * 8 + e] =
+                                (j < joints && k < c) ? f32_to_bf16_host(w[(size_t)j * c + k]) : (uint16_t)0;
+                        }
         }
         if (plan_only) {
             memcpy(blob, host.data(), (size_t)blob_bytes);
@@ -963,6 +982,9 @@ struct hrn_ctx {
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op &op = ops[oi];
             hipError_t e = hipSuccess;
+            // every other launch walks its tensors backwards: it starts on what its producer wrote last, i.e. on the
+            // part most likely still in the Infinity Cache (256 MB; a 256-crop tensor is up to 0.9 GB)
+            const bool rev = alternate && (oi & 1);
             switch (op.kind) {
                 case OP_STEM: {
                     const Tensor &t = tensors[stem_out_t];
@@ -994,14 +1016,14 @@ struct hrn_ctx {
                         e = launch_conv_tap_lds(a, cv.ks, cv.nr, s);
                         break;
                     }
-                    const ConvArgs a = conv_args(cv, nb);
+                    const ConvArgs a = conv_args(cv, nb, rev);
                     e = launch_conv(dtype, a, cv.nr, s);
                     break;
                 }
                 case OP_CONV3_GROUP: {
                     Conv3Group &g = groups[op.idx];
                     if (g.cached_nb != nb) {  // block map depends on the micro-batch size: rebuild on change
-                        g.nblocks = group_blocks(g, nb, &g.map_host);
+                        g.nblocks = group_blocks(g, nb, &g.map_host, rev);
                         e = hipMemcpyAsync(g.map_dev, g.map_host.data(), (size_t)g.nblocks * sizeof(int2),
                                            hipMemcpyHostToDevice, s);
                         if (e != hipSuccess) break;
@@ -1015,7 +1037,7 @@ struct hrn_ctx {
                     DirectGroup &g = dgroups[op.idx];
                     if (g.cached_nb != nb) {  // descriptors (row counts) and block map depend on the micro-batch size
                         g.args_host.clear();
-                        for (int ci : g.conv_idx) g.args_host.push_back(conv_args(convs[ci], nb));
+                        for (int ci : g.conv_idx) g.args_host.push_back(conv_args(convs[ci], nb, rev));
                         g.nblocks = direct_group_blocks(g, nb, &g.map_host);
                         e = hipMemcpyAsync(g.args_dev, g.args_host.data(), g.args_host.size() * sizeof(ConvArgs),
                                            hipMemcpyHostToDevice, s);
@@ -1040,7 +1062,7 @@ struct hrn_ctx {
                     }
                     for (int i = f.nterms; i < 4; ++i) a.t[i] = FuseTerm{nullptr, 0, 0, 0};
                     a.out = row0(f.out_t), a.c = to.c, a.h = to.h, a.w = to.w, a.wp = to.wp, a.hpwp = to.hpwp;
-                    a.m = nb * to.hpwp;
+                    a.m = nb * to.hpwp, a.rev = rev;
                     e = launch_fuse(dtype, a, s);
                     break;
                 }
@@ -1049,6 +1071,7 @@ struct hrn_ctx {
                     HeadArgs a;
                     a.in = row0(head_in_t);
                     a.wgt = (const float *)(blob + head_w_off), a.bias = (const float *)(blob + head_b_off);
+                    a.wimg = (dtype == HRN_BF16 && !disable_head_mfma) ? (const void *)(blob + head_wp_off) : nullptr;
                     a.heatmaps = heatmaps, a.part_val = part_val, a.part_idx = part_idx;
                     a.n = nb, a.c = t.c, a.joints = joints, a.h = t.h, a.w = t.w, a.wp = t.wp, a.hpwp = t.hpwp;
                     a.slabs = head_slabs, a.slab_px = head_slab_px;

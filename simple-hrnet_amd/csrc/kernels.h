@@ -25,6 +25,7 @@ struct ConvArgs {
     int m;                                  // rows to produce = n * out_hpwp
     int ksize, stride, relu;
     int kchunks;                            // padded K / (32 bf16 | 16 f32)
+    int rev;                                // walk the M tiles backwards (see hrn_ctx::alternate)
 };
 
 // LDS-staged 3x3 stride-1 convolution (conv3x3_lds.hip); input and output share one geometry.
@@ -100,11 +101,13 @@ struct FuseArgs {          // out = relu(sum_j term_j) in order j = 0..nterms-1
     void *out;
     int c, h, w, wp, hpwp;
     int m;                 // n * hpwp
+    int rev;               // walk the rows backwards
 };
 
 struct HeadArgs {          // final 1x1 conv (+bias) and per-(crop, joint) partial arg-max
     const void *in;        // fused branch 0, flat padded, c channels
     const float *wgt;      // [joints][c] fp32
+    const void *wimg;      // bf16 mode: MFMA image of the weights, [2 frags][ceil(c/32) chunks][64 lanes][8 bf16]
     const float *bias;     // [joints]
     float *heatmaps;       // (n,joints,h,w) fp32 NCHW or nullptr
     float *part_val;       // [n][joints][slabs]

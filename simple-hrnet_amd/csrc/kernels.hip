@@ -73,15 +73,16 @@ __device__ __forceinline__ f32x4 mma<DT_F32>(f32x4 w, f32x4 x, f32x4 acc) {
 // loop is two chunks long and the kernel is a chain of memory round trips (operands, residual, store); this folds
 // the first two into one.  bf16, even NR only.
 template <int DT, int NR, int MR, bool PRE = false>
-__device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng, const int mtile) {
+__device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng, const int mtile_in) {
     using T = Tr<DT>;
     using vec = typename T::vec;
     using elem = typename T::elem;
     typedef const GLOBAL_AS vec *gvec_p;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
+    if (mtile_in * 64 * MR >= p.m) return;
+    const int mtile = p.rev ? (p.m + 64 * MR - 1) / (64 * MR) - 1 - mtile_in : mtile_in;
     const int m0 = (mtile * 4 + wave) * (16 * MR);
-    if (mtile * 64 * MR >= p.m) return;
     // descriptor pointers may have come from memory (grouped launch): name the address space, or every access
     // through them is a FLAT one
     const GLOBAL_AS elem *__restrict__ in = (const GLOBAL_AS elem *)p.in;
@@ -438,7 +439,8 @@ __global__ __launch_bounds__(256) void fuse_kernel(const FuseArgs p) {
     using T = Tr<DT>;
     using vec = typename T::vec;
     const int cvn = p.c / T::VEC;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long bid = p.rev ? (long)gridDim.x - 1 - blockIdx.x : (long)blockIdx.x;
+    const long idx = bid * 256 + threadIdx.x;
     const long total = (long)p.m * cvn;
     if (idx >= total) return;
     const int q = (int)(idx / cvn), cv = (int)(idx - (long)q * cvn);
@@ -566,10 +568,99 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs p) {
     }
 }
 
+// bf16 mode: the same head on MFMA.  D[joint][pixel] = W[joint][k] * X[k][pixel], joints padded to 32 (two
+// fragments), K = c padded to a multiple of 32 (weights zero there; the x operand is forced to zero too, so stray
+// bytes never meet the matrix unit).  Lane (li, g) ends up with joints 4g..4g+3 and 16+4g..16+4g+3 of pixel li:
+// a running (max, first index) per slot over the wave's 16 pixel fragments, then a 16-lane butterfly over li, then
+// the four waves through LDS.  wimg = [fragment][chunk][lane][8 bf16] (hrnet_mi355.cpp: load_weights).
+__global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs p) {
+    __shared__ float red_v[4 * kMaxJoints];
+    __shared__ int red_i[4 * kMaxJoints];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int slab = blockIdx.x, n = blockIdx.y;
+    const int hw = p.h * p.w;
+    const int kch = (p.c + 31) >> 5;
+    const GLOBAL_AS unsigned short *__restrict__ in = (const GLOBAL_AS unsigned short *)p.in;
+    const GLOBAL_AS s16x8 *__restrict__ wimg = (const GLOBAL_AS s16x8 *)p.wimg;
+    float bias[8];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = f * 16 + 4 * g + r;
+            bias[f * 4 + r] = j < p.joints ? p.bias[j] : 0.f;
+        }
+    float bv[8];
+    int bi[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bv[t] = -INFINITY, bi[t] = 0x7fffffff;
+
+    const int px_per_wave = p.slab_px / 4;
+    for (int it = 0; it < px_per_wave / 16; ++it) {
+        const int px0 = slab * p.slab_px + wave * px_per_wave + it * 16;
+        if (px0 >= hw) break;  // wave-uniform
+        const int px = px0 + li;
+        const bool live = px < hw;
+        const int pc = live ? px : hw - 1;
+        const int r = pc / p.w, c = pc - r * p.w;
+        const GLOBAL_AS unsigned short *row = in + ((size_t)n * p.hpwp + r * p.wp + c) * p.c;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        for (int kc = 0; kc < kch; ++kc) {
+            const int k0 = kc * 32 + g * 8;
+            s16x8 x = {};
+            if (k0 < p.c) x = *(const GLOBAL_AS s16x8 *)(row + k0);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) acc[f] = mma<DT_BF16>(wimg[(f * kch + kc) * 64 + lane], x, acc[f]);
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = f * 4 + q, j = f * 16 + 4 * g + q;
+                const float v = acc[f][q] + bias[t];
+                if (live && j < p.joints) {
+                    if (p.heatmaps) p.heatmaps[((size_t)n * p.joints + j) * hw + px] = v;
+                    if (v > bv[t]) bv[t] = v, bi[t] = px;  // px grows with `it`: strict > keeps the first maximum
+                }
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        float v = bv[t];
+        int i = bi[t];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {  // over li: lanes of one k-group
+            const float ov = __shfl_xor(v, off);
+            const int oi = __shfl_xor(i, off);
+            if (better(ov, oi, v, i)) v = ov, i = oi;
+        }
+        const int j = (t >> 2) * 16 + 4 * g + (t & 3);
+        if (li == 0 && j < kMaxJoints) red_v[wave * kMaxJoints + j] = v, red_i[wave * kMaxJoints + j] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x < p.joints) {
+        const int j = threadIdx.x;
+        float v = red_v[j];
+        int i = red_i[j];
+        for (int w = 1; w < 4; ++w)
+            if (better(red_v[w * kMaxJoints + j], red_i[w * kMaxJoints + j], v, i)) {
+                v = red_v[w * kMaxJoints + j];
+                i = red_i[w * kMaxJoints + j];
+            }
+        p.part_val[((size_t)n * p.joints + j) * p.slabs + slab] = v;
+        p.part_idx[((size_t)n * p.joints + j) * p.slabs + slab] = i;
+    }
+}
+
 hipError_t launch_head(int dtype, const HeadArgs &a, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
     if (a.joints > kMaxJoints) return hipErrorInvalidValue;
     dim3 grid(a.slabs, a.n);
+    if (dtype == DT_BF16 && a.wimg && a.slab_px % 64 == 0) {
+        hipLaunchKernelGGL(head_mfma_kernel, grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     const size_t shm = sizeof(float) * ((size_t)a.joints * a.c + 4 * kMaxJoints) + sizeof(int) * 4 * kMaxJoints;
     if (dtype == DT_BF16)
         hipLaunchKernelGGL(head_kernel<DT_BF16>, grid, dim3(256), shm, s, a);
