@@ -204,13 +204,24 @@ def main():
             sub_flops = sum(i.flops for i, _ in sub) * nb
             sub_ms = sum(ms for _, ms in sub)
             ach = sub_flops / (sub_ms * 1e-3) / 1e12
+            # algorithmic HBM bytes of the same launches: input + output (+ residual) activations and the weights
+            esz = 2 if a.dtype == "bf16" else 4
+            sub_bytes = sum(((2 + i.has_residual) * i.cout * i.out_h * i.out_w * nb + 9 * i.cin * i.cout) * esz for i, _ in sub)
+            # HBM-side traffic of the same kernel from the committed PMC passes (cannot be collected live)
+            traffic, traffic_src = None, None
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+            if a.c == 48 and a.dtype == "bf16" and nb == 256 and (a.height, a.width) == (384, 288) and os.path.exists(pmc):
+                with open(pmc) as f:
+                    traffic = json.load(f)["traffic_bytes_per_launch"]
+                traffic_src = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
             all_ms = sum(conv_ms) + sum(other.values())
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": "conv3x3_lds_kernel: stage-3/4 BasicBlock 3x3 convs, %d convs in %d grouped launches"
                           % (len(sub), launches),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": None,
+                "traffic": traffic, "traffic_unit": "bytes per grouped launch", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(sub_bytes / launches),
                 "flops_per_launch": round(sub_flops / launches / 1e9, 3), "flops_unit": "GFLOP (algorithmic, 2*MAC)",
                 "avg_launch_ms": round(sub_ms / launches, 4),
                 "timing": "HIP events on the launch stream around every kernel of one pass of %d crops" % nb,

@@ -240,3 +240,58 @@ def test_repeatability_full_size(pkg):
     assert torch.equal(hm_t, hm0[256:]) and torch.equal(p_t, p0[256:])
     assert bool(torch.isfinite(hm0).all())
     net.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_scheduling_variants_are_bit_identical(pkg, dtype, monkeypatch):
+    """Launch grouping, block order and walk direction only reschedule work: every variant must give the same bits.
+    (The switches are read when the handle is created.)"""
+    c, h, w, n = 48, 128, 96, 5
+    crops = torch.from_numpy(pkg.synth_crops(n, h, w, seed=21)).cuda()
+    boxes = pkg.synth_boxes(n, seed=22)
+
+    def run(env):
+        for k in ("HRN_DISABLE_DGROUP", "HRN_DGROUP_NR", "HRN_ALTERNATE", "HRN_DISABLE_GROUP", "HRN_BLOCK_ORDER",
+                  "HRN_LONG_FACTOR"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = _engine(pkg, c, h, w, dtype, max_batch=4, seed=3)   # 5 crops, micro-batch 4: ragged second pass
+        hm, pts = net.predict_crops(crops, boxes, return_heatmaps=True)
+        out = hm.cpu().numpy(), pts.cpu().numpy()
+        net.close()
+        return out
+
+    base = run({})
+    for env in ({"HRN_DISABLE_DGROUP": "1"}, {"HRN_DGROUP_NR": "0"}, {"HRN_ALTERNATE": "0"}, {"HRN_DISABLE_GROUP": "1"},
+                {"HRN_BLOCK_ORDER": "0", "HRN_LONG_FACTOR": "1"}):
+        hm, pts = run(env)
+        np.testing.assert_array_equal(hm, base[0], err_msg=str(env))
+        np.testing.assert_array_equal(pts, base[1], err_msg=str(env))
+
+
+def test_bf16_head_mfma_vs_fp32_weight_head(pkg, monkeypatch):
+    """The MFMA head rounds final_layer's weights to bf16; the VALU head keeps them fp32.  Same activations in both:
+    the heat-maps may differ by the weight rounding only (2^-9 relative per term)."""
+    c, h, w, n = 32, 128, 96, 3
+    crops = torch.from_numpy(pkg.synth_crops(n, h, w, seed=31)).cuda()
+    boxes = pkg.synth_boxes(n, seed=32)
+    monkeypatch.delenv("HRN_DISABLE_HEAD_MFMA", raising=False)
+    a = _engine(pkg, c, h, w, "bf16", max_batch=4, seed=5)
+    hm_a, pts_a = a.predict_crops(crops, boxes, return_heatmaps=True)
+    only_pts = a.predict_crops(crops, boxes)                      # heat-map write-out off: same arg-max path
+    assert torch.equal(only_pts, pts_a)
+    monkeypatch.setenv("HRN_DISABLE_HEAD_MFMA", "1")
+    b = _engine(pkg, c, h, w, "bf16", max_batch=4, seed=5)
+    hm_b, pts_b = b.predict_crops(crops, boxes, return_heatmaps=True)
+    hm_a, hm_b = hm_a.cpu().numpy(), hm_b.cpu().numpy()
+    scale = np.abs(hm_b).max()
+    assert np.abs(hm_a - hm_b).max() <= 0.01 * scale + 1e-3
+    # arg-max of the MFMA head is the first maximum of ITS OWN heat-maps (decode on the GPU == numpy on the host)
+    flat = hm_a.reshape(n, 17, -1)
+    idx = flat.argmax(-1)
+    T = _oracle()
+    ref = T.decode_heatmaps(hm_a, boxes)
+    np.testing.assert_array_equal(pts_a.cpu().numpy()[..., :2], ref[..., :2])
+    assert idx.shape == (n, 17)
+    a.close(), b.close()
