@@ -44,12 +44,8 @@ struct ConvOp {
     int in_t, out_t, res_t;
     int cin, cout, k, stride, relu;
     int kpad, kchunks, nr;
-    int algo = 0;          // 0 = generic direct kernel, 1 = LDS-staged 3x3 s1 (conv3x3_lds.hip)
+    int algo = 0;          // 0 = generic kernel (kernels.hip), 1 = pipelined LDS-staged 3x3 stride 1 (conv3x3_lds.hip)
     int ks = 0, slices = 0, ntiles = 0, nch = 0;
-    std::vector<TapSlice> tap;     // algo 2: K slices (src / w pointers are filled in at allocation time)
-    std::vector<int64_t> tap_woff; // algo 2: blob offset of each slice's packed weights
-    TapSlice *tap_dev = nullptr;
-    int slab_bytes = 0;
     int64_t w_off = 0, w_bytes = 0, b_off = 0;
     double flops = 0;
 };
@@ -133,7 +129,6 @@ struct hrn_ctx {
 
     bool disable_lds = getenv("HRN_DISABLE_LDS") != nullptr;
     bool disable_group = getenv("HRN_DISABLE_GROUP") != nullptr;
-    bool disable_tap = getenv("HRN_DISABLE_TAP") != nullptr;
     bool disable_dgroup = getenv("HRN_DISABLE_DGROUP") != nullptr;
     // 1: convolutions that read the same tensor share one cout-tile width so that they can share a launch (and L2)
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
@@ -141,7 +136,6 @@ struct hrn_ctx {
     bool disable_stem_mfma = getenv("HRN_DISABLE_STEM_MFMA") != nullptr;
     bool disable_head_mfma = getenv("HRN_DISABLE_HEAD_MFMA") != nullptr;
     bool direct_nr6 = getenv("HRN_DIRECT_NR6") ? atoi(getenv("HRN_DIRECT_NR6")) != 0 : true;
-    bool tap_stride2 = getenv("HRN_TAP_STRIDE2") != nullptr;  // stride-2 via the tap kernel (slower than direct so far)
     int half_stages_per_block = getenv("HRN_HALF_STAGES") ? atoi(getenv("HRN_HALF_STAGES")) : 8;
     bool alternate = getenv("HRN_ALTERNATE") ? atoi(getenv("HRN_ALTERNATE")) != 0 : true;
     int block_order = getenv("HRN_BLOCK_ORDER") ? atoi(getenv("HRN_BLOCK_ORDER")) : 1;
@@ -218,71 +212,10 @@ struct hrn_ctx {
             op.algo = 1, op.ks = lds_ks, op.nr = lds_nrb;
             op.slices = op.cin / lds_ks, op.ntiles = cout / (16 * lds_nrb), op.nch = (9 * lds_ks + 31) / 32;
             op.kpad = op.nch * 32 * op.slices;
-        } else if (dtype == HRN_BF16 && k == 3 && (op.cin % 48 == 0 || op.cin % 32 == 0) &&
-                   (cout % 64 == 0 || cout % 48 == 0) && !disable_tap && (stride == 1 || tap_stride2)) {
-            build_tap_slices(op, ti, oh, ow);
         }
         convs.push_back(op);
         if (emit) emit_convs({(int)convs.size() - 1});
         return op.out_t;
-    }
-
-    // algo 2 (conv_tap_lds.hip): cut K into (view, channel range, tap list) slices
-    void build_tap_slices(ConvOp &op, const Tensor &ti, int oh, int ow) {
-        op.algo = 2;
-        op.ks = op.cin % 48 == 0 ? 48 : 32;
-        op.nr = op.cout % 64 == 0 ? 4 : 3;
-        op.ntiles = op.cout / (16 * op.nr);
-        const int wpo = ow + 1;
-        const int nch_slices = op.cin / op.ks;
-        int kpad = 0, max_rows = 0;
-        auto push = [&](TapSlice sl) {
-            sl.nchunks = (sl.ntaps * op.ks + 31) / 32;
-            sl.minoff = sl.maxoff = sl.tap_off[0];
-            for (int t = 0; t < sl.ntaps; ++t) {
-                if (sl.tap_off[t] < sl.minoff) sl.minoff = sl.tap_off[t];
-                if (sl.tap_off[t] > sl.maxoff) sl.maxoff = sl.tap_off[t];
-            }
-            for (int t = sl.ntaps; t < 9; ++t) sl.tap_off[t] = sl.tap_off[sl.ntaps - 1], sl.tap_id[t] = -1;
-            const int rows = 256 + sl.maxoff - sl.minoff + 1;
-            if (rows > max_rows) max_rows = rows;
-            kpad += sl.nchunks * 32;
-            op.tap.push_back(sl);
-        };
-        if (op.stride == 1) {
-            for (int cs = 0; cs < nch_slices; ++cs) {
-                TapSlice sl{};
-                sl.mode = 0, sl.src_wp = ti.wp, sl.src_hpwp = ti.hpwp, sl.src_c = ti.c, sl.ci0 = cs * op.ks;
-                sl.ntaps = 9;
-                for (int t = 0; t < 9; ++t) sl.tap_off[t] = (t / 3 - 1) * wpo + (t % 3 - 1), sl.tap_id[t] = t;
-                push(sl);
-            }
-        } else {
-            for (int a = 0; a < 2; ++a)
-                for (int b = 0; b < 2; ++b)
-                    for (int cs = 0; cs < nch_slices; ++cs) {
-                        TapSlice sl{};
-                        sl.mode = 1, sl.a = a, sl.b = b;
-                        sl.src_wp = ti.wp, sl.src_hpwp = ti.hpwp, sl.src_c = ti.c, sl.ci0 = cs * op.ks;
-                        // kh-1 = 2*dh + a: a == 0 -> kh = 1 (dh 0); a == 1 -> kh = 0 (dh -1), kh = 2 (dh 0)
-                        const int khs[2][2] = {{1, -1}, {0, 2}}, dhs[2][2] = {{0, 0}, {-1, 0}};
-                        sl.ntaps = 0;
-                        for (int x = 0; x < 2; ++x)
-                            for (int y = 0; y < 2; ++y) {
-                                const int kh = khs[a][x], kw = khs[b][y];
-                                if (kh < 0 || kw < 0) continue;
-                                sl.tap_off[sl.ntaps] = dhs[a][x] * wpo + dhs[b][y];
-                                sl.tap_id[sl.ntaps] = kh * 3 + kw;
-                                ++sl.ntaps;
-                            }
-                        push(sl);
-                    }
-        }
-        op.kpad = kpad;
-        op.slices = (int)op.tap.size();
-        const int upr = op.ks / 8;
-        op.slab_bytes = ((max_rows * upr + 63) / 64) * 1024;
-        (void)oh;
     }
 
     // emit a set of mutually independent convolutions: one grouped launch when all of them run on the
@@ -489,17 +422,8 @@ struct hrn_ctx {
         stem_wp_off = off, off = align_up(off + 4 * 1024, 256);  // bf16 MFMA image of conv1 (stem_mfma_kernel)
         for (auto &cv : convs) {
             cv.w_off = off;
-            if (cv.algo == 2) {
-                cv.w_bytes = 0;
-                cv.tap_woff.clear();
-                for (auto &sl : cv.tap) {
-                    cv.tap_woff.push_back(cv.w_off + cv.w_bytes);
-                    cv.w_bytes += (int64_t)cv.ntiles * sl.nchunks * cv.nr * 1024;
-                }
-            } else {
-                cv.w_bytes = cv.algo == 1 ? (int64_t)cv.ntiles * cv.slices * cv.nch * cv.nr * 1024
-                                          : (int64_t)(cv.cout / 16) * cv.kchunks * 1024;
-            }
+            cv.w_bytes = cv.algo == 1 ? (int64_t)cv.ntiles * cv.slices * cv.nch * cv.nr * 1024
+                                      : (int64_t)(cv.cout / 16) * cv.kchunks * 1024;
             off = align_up(off + cv.w_bytes, 256);
             cv.b_off = off;
             off = align_up(off + cv.cout * 4, 256);
@@ -537,7 +461,7 @@ struct hrn_ctx {
         }
         if (!hip_ok(hipMalloc((void **)&blob, (size_t)blob_bytes), "hipMalloc(weights)")) return false;
         if (!hip_ok(hipMemset(blob, 0, (size_t)blob_bytes), "hipMemset(weights)")) return false;
-        if (!setup_groups() || !setup_dgroups() || !setup_tap_tables()) return false;
+        if (!setup_groups() || !setup_dgroups()) return false;
         if (!hip_ok(hipMalloc((void **)&part_val, (size_t)part * 4), "hipMalloc(part_val)")) return false;
         if (!hip_ok(hipMalloc((void **)&part_idx, (size_t)part * 4), "hipMalloc(part_idx)")) return false;
         return hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
@@ -686,21 +610,6 @@ struct hrn_ctx {
         return true;
     }
 
-    bool setup_tap_tables() {
-        for (auto &cv : convs) {
-            if (cv.algo != 2) continue;
-            for (size_t si = 0; si < cv.tap.size(); ++si) {
-                cv.tap[si].src = row0(cv.in_t);
-                cv.tap[si].w = blob + cv.tap_woff[si];
-            }
-            const size_t bytes = cv.tap.size() * sizeof(TapSlice);
-            if (!hip_ok(hipMalloc((void **)&cv.tap_dev, bytes), "hipMalloc(tap slices)")) return false;
-            if (!hip_ok(hipMemcpy(cv.tap_dev, cv.tap.data(), bytes, hipMemcpyHostToDevice), "hipMemcpy(tap slices)"))
-                return false;
-        }
-        return true;
-    }
-
     bool setup_groups() {
         size_t nprob = 0;
         for (auto &g : groups) {
@@ -753,8 +662,6 @@ struct hrn_ctx {
             if (part_val) (void)hipFree(part_val);
             if (part_idx) (void)hipFree(part_idx);
             if (probs_dev) (void)hipFree(probs_dev);
-            for (auto &cv : convs)
-                if (cv.tap_dev) (void)hipFree(cv.tap_dev);
             for (auto &g : groups)
                 if (g.map_dev) (void)hipFree(g.map_dev);
             for (auto &g : dgroups) {
@@ -853,9 +760,7 @@ struct hrn_ctx {
                     for (int t = 0; t < kk; ++t)
                         wf[(size_t)co * K + t * cv.cin + ci] =
                             (float)((double)w[((size_t)co * cv.cin + ci) * kk + t] * scale[co]);
-            if (cv.algo == 2)
-                pack_conv_tap(cv, wf.data(), K, host.data());
-            else if (cv.algo == 1)
+            if (cv.algo == 1)
                 pack_conv_lds(cv, wf.data(), K, host.data() + cv.w_off);
             else
                 pack_conv(cv, wf.data(), K, host.data() + cv.w_off);
@@ -918,33 +823,6 @@ struct hrn_ctx {
         }
     }
 
-    // Per-slice images for conv_tap_lds_kernel: slice block = [cout tile][chunk][frag][lane][8 bf16] with
-    // k_local = t*KS + ci_local, t indexing the slice's own tap list; zero beyond ntaps*KS.
-    void pack_conv_tap(const ConvOp &cv, const float *wf, int K, char *blob_host) const {
-        const int KS = cv.ks, NRB = cv.nr;
-        for (size_t si = 0; si < cv.tap.size(); ++si) {
-            const TapSlice &sl = cv.tap[si];
-            uint16_t *base = (uint16_t *)(blob_host + cv.tap_woff[si]);
-            for (int t = 0; t < cv.ntiles; ++t)
-                for (int c = 0; c < sl.nchunks; ++c)
-                    for (int j = 0; j < NRB; ++j)
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int li = lane & 15, g = lane >> 4;
-                            const int co = t * 16 * NRB + (li >> 2) * 4 * NRB + j * 4 + (li & 3);
-                            uint16_t *d = base + ((((size_t)t * sl.nchunks + c) * NRB + j) * 64 + lane) * 8;
-                            for (int e = 0; e < 8; ++e) {
-                                const int kl = 32 * c + 8 * g + e;
-                                float v = 0.f;
-                                if (kl < sl.ntaps * KS) {
-                                    const int tt = kl / KS, cil = kl % KS;
-                                    v = wf[(size_t)co * K + sl.tap_id[tt] * cv.cin + sl.ci0 + cil];
-                                }
-                                d[e] = f32_to_bf16_host(v);
-                            }
-                        }
-        }
-    }
-
     // Slice-major image for conv3x3_lds_kernel: block (cout tile t, slice s) is the exact LDS image
     // [chunk c][frag j][lane][8 bf16]; within a slice k = tap*KS + ci_local, zero beyond 9*KS.
     void pack_conv_lds(const ConvOp &cv, const float *wf, int K, char *dst) const {
@@ -999,23 +877,6 @@ struct hrn_ctx {
                 }
                 case OP_CONV: {
                     const ConvOp &cv = convs[op.idx];
-                    const Tensor &to = tensors[cv.out_t];
-                    if (cv.algo == 2) {
-                        TapConvArgs a;
-                        a.out = row0(cv.out_t), a.bias = (const float *)(blob + cv.b_off);
-                        a.res = cv.res_t >= 0 ? row0(cv.res_t) : nullptr;
-                        a.slices = cv.tap_dev, a.nslices = (int)cv.tap.size();
-                        a.cout = cv.cout, a.relu = cv.relu;
-                        a.h = to.h, a.wd = to.w, a.wp = to.wp, a.hpwp = to.hpwp, a.m = nb * to.hpwp;
-                        a.ntiles = cv.ntiles, a.slab_bytes = cv.slab_bytes;
-                        a.max_chunks = 1;
-                        for (auto &sl : cv.tap)
-                            if (sl.nchunks > a.max_chunks) a.max_chunks = sl.nchunks;
-                        fast_div(to.hpwp, &a.magic_hpwp, &a.shift_hpwp);
-                        fast_div(to.wp, &a.magic_wp, &a.shift_wp);
-                        e = launch_conv_tap_lds(a, cv.ks, cv.nr, s);
-                        break;
-                    }
                     const ConvArgs a = conv_args(cv, nb, rev);
                     e = launch_conv(dtype, a, cv.nr, s);
                     break;

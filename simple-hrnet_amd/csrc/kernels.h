@@ -49,37 +49,6 @@ struct Conv3Problem {
 };
 int conv3x3_lds_bm(int ks, int nrb, int wp);
 
-// Tap-list LDS-staged 3x3 convolution (conv_tap_lds.hip): stride-2 convs and stride-1 convs outside the
-// BasicBlock shapes.  One K slice = (source view, channel range, tap list).
-struct TapSlice {
-    const void *src;      // row 0 of the source tensor
-    const void *w;        // packed weights of this slice: [cout tile][chunk][frag][lane][16 B]
-    int mode;             // 0: stride 1 (view = the tensor), 1: stride 2 (view = phase (a,b) gathered on the fly)
-    int a, b;
-    int src_wp, src_hpwp, src_c;
-    int ci0;              // first input channel of the slice
-    int ntaps, nchunks;   // taps in this slice; K chunks = ceil(ntaps * KS / 32)
-    int minoff, maxoff;   // min / max tap row shift (output geometry)
-    int tap_off[9];       // row shift of tap t
-    int tap_id[9];        // kh*3 + kw of tap t (host-side packing only)
-};
-struct TapConvArgs {
-    void *out;
-    const float *bias;
-    const void *res;
-    const TapSlice *slices;  // device array
-    int nslices;
-    int cout, relu;
-    int h, wd, wp, hpwp;     // output geometry
-    int m;                   // rows to produce = n * hpwp
-    int ntiles;              // cout / (16*NRB)
-    int slab_bytes;          // LDS bytes reserved for the largest slab of this conv (multiple of 1024)
-    int max_chunks;          // largest K-chunk count of a slice (sizes the LDS weight stage)
-    unsigned magic_hpwp, magic_wp;
-    int shift_hpwp, shift_wp;
-};
-hipError_t launch_conv_tap_lds(const TapConvArgs &a, int ks, int nrb, hipStream_t s);
-
 struct StemArgs {          // conv1 3->64 3x3 s2 + BN + ReLU, NCHW fp32 in, flat padded out
     const float *images;   // (n,3,H,W)
     void *out;

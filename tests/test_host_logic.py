@@ -90,56 +90,10 @@ def _unpack_lds(net, info):
     return out
 
 
-def _tap_slices(info):
-    """python mirror of hrn_ctx::build_tap_slices: [(tap ids, ci0)] per K slice of the tap-list kernel"""
-    ks = info.ks
-    out = []
-    if info.stride == 1:
-        for cs in range(info.cin // ks):
-            out.append((list(range(9)), cs * ks))
-    else:
-        khs = {0: [1], 1: [0, 2]}
-        for a in (0, 1):
-            for b in (0, 1):
-                for cs in range(info.cin // ks):
-                    out.append(([kh * 3 + kw for kh in khs[a] for kw in khs[b]], cs * ks))
-    return out
-
-
-def _unpack_tap(net, info):
-    """inverse of the per-slice images of conv_tap_lds_kernel: [slice][cout tile][chunk][frag][lane][8 bf16]"""
-    raw = net.read_blob(info.w_offset, info.w_bytes)
-    vals = (raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32)
-    ks, nrb = info.ks, info.nr
-    ntiles = info.cout // (16 * nrb)
-    out = np.zeros((info.cout, 9 * info.cin), np.float32)
-    pos = 0
-    for taps, ci0 in _tap_slices(info):
-        nch = (len(taps) * ks + 31) // 32
-        blk = vals[pos:pos + ntiles * nch * nrb * 512].reshape(ntiles, nch, nrb, 64, 8)
-        pos += ntiles * nch * nrb * 512
-        for t in range(ntiles):
-            for c in range(nch):
-                for j in range(nrb):
-                    for lane in range(64):
-                        li, g = lane & 15, lane >> 4
-                        co = t * 16 * nrb + (li >> 2) * 4 * nrb + j * 4 + (li & 3)
-                        for e in range(8):
-                            kl = 32 * c + 8 * g + e
-                            if kl < len(taps) * ks:
-                                out[co, taps[kl // ks] * info.cin + ci0 + kl % ks] = blk[t, c, j, lane, e]
-                            else:
-                                assert blk[t, c, j, lane, e] == 0
-    assert pos == len(vals)
-    return out
-
-
 def _unpack(net, info, dtype):
     """inverse of the documented fragment-major layout"""
     if info.algo == 1:
         return _unpack_lds(net, info)
-    if info.algo == 2:
-        return _unpack_tap(net, info)
     kc, vec = (32, 8) if dtype == "bf16" else (16, 4)
     raw = net.read_blob(info.w_offset, info.w_bytes)
     if dtype == "bf16":
