@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libhrnet_mi355.so")
-SOURCES = ["kernels.hip", "conv3x3_lds.hip", "hrnet_mi355.cpp"]
+SOURCES = ["kernels.hip", "conv3x3_lds.hip", "bottleneck_chain.hip", "hrnet_mi355.cpp"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(INCLUDE, "hrnet_mi355.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 

@@ -37,7 +37,7 @@ struct Buffer {
     bool in_use = false;
 };
 
-enum OpKind { OP_STEM, OP_CONV, OP_CONV3_GROUP, OP_CONV_GROUP, OP_FUSE, OP_HEAD, OP_DECODE };
+enum OpKind { OP_STEM, OP_CONV, OP_CONV3_GROUP, OP_CONV_GROUP, OP_CHAIN, OP_FUSE, OP_HEAD, OP_DECODE };
 
 struct ConvOp {
     std::string conv, bn;  // state_dict prefixes ("" bn => plain bias conv)
@@ -118,6 +118,7 @@ struct hrn_ctx {
     std::vector<FuseOp> fuses;
     std::vector<Conv3Group> groups;
     std::vector<DirectGroup> dgroups;
+    std::vector<std::pair<int, int>> chains;  // (conv3 of Bottleneck b, conv1 of Bottleneck b+1): one launch
     Conv3Problem *probs_dev = nullptr;
     std::vector<Op> ops;
     int stem_out_t = -1, head_in_t = -1;
@@ -130,6 +131,7 @@ struct hrn_ctx {
     bool disable_lds = getenv("HRN_DISABLE_LDS") != nullptr;
     bool disable_group = getenv("HRN_DISABLE_GROUP") != nullptr;
     bool disable_dgroup = getenv("HRN_DISABLE_DGROUP") != nullptr;
+    bool disable_chain = getenv("HRN_DISABLE_CHAIN") != nullptr;
     // 1: convolutions that read the same tensor share one cout-tile width so that they can share a launch (and L2)
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
@@ -377,20 +379,34 @@ struct hrn_ctx {
         int x = add_conv("conv2", "bn2", stem_out_t, 64, 3, 2, 1);  // hrnet.py:161-163
         release(stem_out_t);
         char buf[96];
+        int o1_next = -1;  // conv1 output of the next Bottleneck when the previous one already produced it
         for (int b = 0; b < 4; ++b) {  // layer1: Bottleneck x4, modules.py:20-40
             snprintf(buf, sizeof buf, "layer1.%d", b);
             const std::string p = buf;
-            std::vector<int> first;  // conv1 and the projection shortcut both read x: one launch
-            const int o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1, -1, false);
-            first.push_back((int)convs.size() - 1);
-            int r = x;
-            if (b == 0) {
+            int o1 = o1_next, r = x;
+            if (b == 0) {  // conv1 and the projection shortcut both read x: one launch
+                o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1, -1, false);
                 r = add_conv(p + ".downsample.0", p + ".downsample.1", x, 256, 1, 1, 0, -1, false);
-                first.push_back((int)convs.size() - 1);
+                emit_convs({(int)convs.size() - 2, (int)convs.size() - 1});
+            } else if (o1 < 0) {
+                o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1);
             }
-            emit_convs(first);
             const int o2 = add_conv(p + ".conv2", p + ".bn2", o1, 64, 3, 1, 1);
-            const int o3 = add_conv(p + ".conv3", p + ".bn3", o2, 256, 1, 1, 1, r);
+            int o3;
+            o1_next = -1;
+            if (dtype == HRN_BF16 && !disable_chain && b < 3) {
+                // conv3 (+shortcut, ReLU) of this block and conv1 (+ReLU) of the next in one pass: the 256-channel
+                // tensor is written once and never read back by a 1x1 conv (bottleneck_chain.hip)
+                snprintf(buf, sizeof buf, "layer1.%d", b + 1);
+                const std::string pn = buf;
+                o3 = add_conv(p + ".conv3", p + ".bn3", o2, 256, 1, 1, 1, r, false, 2);
+                const int i3 = (int)convs.size() - 1;
+                o1_next = add_conv(pn + ".conv1", pn + ".bn1", o3, 64, 1, 1, 1, -1, false, 4);
+                chains.push_back({i3, (int)convs.size() - 1});
+                ops.push_back({OP_CHAIN, (int)chains.size() - 1});
+            } else {
+                o3 = add_conv(p + ".conv3", p + ".bn3", o2, 256, 1, 1, 1, r);
+            }
             release(o1), release(o2);
             if (b == 0) release(r);
             release(x);
@@ -911,6 +927,17 @@ struct hrn_ctx {
                     e = launch_conv_group(dtype, g.args_dev, g.map_dev, g.nblocks, g.nr, s);
                     break;
                 }
+                case OP_CHAIN: {
+                    const ConvOp &c3 = convs[chains[op.idx].first], &c1 = convs[chains[op.idx].second];
+                    const Tensor &to = tensors[c3.out_t];
+                    ChainArgs a;
+                    a.in = row0(c3.in_t), a.res = row0(c3.res_t), a.out_y = row0(c3.out_t), a.out_t = row0(c1.out_t);
+                    a.w3 = blob + c3.w_off, a.b3 = (const float *)(blob + c3.b_off);
+                    a.w1 = blob + c1.w_off, a.b1 = (const float *)(blob + c1.b_off);
+                    a.m = nb * to.hpwp, a.h = to.h, a.w = to.w, a.wp = to.wp, a.hpwp = to.hpwp, a.rev = rev;
+                    e = launch_bottleneck_chain(a, s);
+                    break;
+                }
                 case OP_FUSE: {
                     const FuseOp &f = fuses[op.idx];
                     const Tensor &to = tensors[f.out_t];
@@ -1148,6 +1175,10 @@ int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms
                 }
                 for (size_t k = 0; k < g.conv_idx.size(); ++k)
                     if (conv_ms && g.conv_idx[k] < conv_ms_len) conv_ms[g.conv_idx[k]] = (float)(ms * wgt[k] / tot);
+            } else if (op.kind == OP_CHAIN) {  // two 1x1 convs of equal FLOPs
+                const std::pair<int, int> &ch = h->chains[op.idx];
+                if (conv_ms && ch.first < conv_ms_len) conv_ms[ch.first] = ms * 0.5f;
+                if (conv_ms && ch.second < conv_ms_len) conv_ms[ch.second] = ms * 0.5f;
             } else if (other_ms) {
                 const int slot = op.kind == OP_STEM ? 0 : op.kind == OP_FUSE ? 1 : op.kind == OP_HEAD ? 2 : 3;
                 other_ms[slot] += ms;

@@ -49,6 +49,21 @@ struct Conv3Problem {
 };
 int conv3x3_lds_bm(int ks, int nrb, int wp);
 
+// layer1: conv3 (+shortcut, ReLU) of one Bottleneck and conv1 (+ReLU) of the next in one pass (bottleneck_chain.hip)
+struct ChainArgs {
+    const void *in;        // conv2 output of block b: [rows][64]
+    const void *res;       // shortcut of block b: [rows][256]
+    void *out_y;           // block b output: [rows][256]
+    void *out_t;           // conv1 output of block b+1: [rows][64]
+    const void *w3;        // 256 x 64, generic fragment image with NR = 2
+    const float *b3;
+    const void *w1;        // 64 x 256, generic fragment image with NR = 4
+    const float *b1;
+    int m, h, w, wp, hpwp; // rows to produce = n*hpwp; geometry for the pad mask
+    int rev;
+};
+hipError_t launch_bottleneck_chain(const ChainArgs &a, hipStream_t s);
+
 struct StemArgs {          // conv1 3->64 3x3 s2 + BN + ReLU, NCHW fp32 in, flat padded out
     const float *images;   // (n,3,H,W)
     void *out;
