@@ -118,7 +118,10 @@ struct hrn_ctx {
     std::vector<FuseOp> fuses;
     std::vector<Conv3Group> groups;
     std::vector<DirectGroup> dgroups;
-    std::vector<std::pair<int, int>> chains;  // (conv3 of Bottleneck b, conv1 of Bottleneck b+1): one launch
+    struct Chain {
+        int conv3, conv1, ds;  // conv3 of Bottleneck b, conv1 of Bottleneck b+1, projection shortcut folded in (or -1)
+    };
+    std::vector<Chain> chains;
     Conv3Problem *probs_dev = nullptr;
     std::vector<Op> ops;
     int stem_out_t = -1, head_in_t = -1;
@@ -132,6 +135,7 @@ struct hrn_ctx {
     bool disable_group = getenv("HRN_DISABLE_GROUP") != nullptr;
     bool disable_dgroup = getenv("HRN_DISABLE_DGROUP") != nullptr;
     bool disable_chain = getenv("HRN_DISABLE_CHAIN") != nullptr;
+    bool disable_chain_ds = getenv("HRN_DISABLE_CHAIN_DS") != nullptr;
     // 1: convolutions that read the same tensor share one cout-tile width so that they can share a launch (and L2)
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
@@ -384,7 +388,15 @@ struct hrn_ctx {
             snprintf(buf, sizeof buf, "layer1.%d", b);
             const std::string p = buf;
             int o1 = o1_next, r = x;
-            if (b == 0) {  // conv1 and the projection shortcut both read x: one launch
+            const bool chain = dtype == HRN_BF16 && !disable_chain && b < 3;
+            int ds_idx = -1;
+            if (b == 0 && chain && !disable_chain_ds) {
+                // the projection shortcut is computed inside the chain kernel: its 256-channel tensor never exists
+                o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1);
+                r = add_conv(p + ".downsample.0", p + ".downsample.1", x, 256, 1, 1, 0, -1, false, 2);
+                ds_idx = (int)convs.size() - 1;
+                release(r);  // never written: hand the buffer back at once
+            } else if (b == 0) {  // conv1 and the projection shortcut both read x: one launch
                 o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1, -1, false);
                 r = add_conv(p + ".downsample.0", p + ".downsample.1", x, 256, 1, 1, 0, -1, false);
                 emit_convs({(int)convs.size() - 2, (int)convs.size() - 1});
@@ -394,7 +406,7 @@ struct hrn_ctx {
             const int o2 = add_conv(p + ".conv2", p + ".bn2", o1, 64, 3, 1, 1);
             int o3;
             o1_next = -1;
-            if (dtype == HRN_BF16 && !disable_chain && b < 3) {
+            if (chain) {
                 // conv3 (+shortcut, ReLU) of this block and conv1 (+ReLU) of the next in one pass: the 256-channel
                 // tensor is written once and never read back by a 1x1 conv (bottleneck_chain.hip)
                 snprintf(buf, sizeof buf, "layer1.%d", b + 1);
@@ -402,13 +414,13 @@ struct hrn_ctx {
                 o3 = add_conv(p + ".conv3", p + ".bn3", o2, 256, 1, 1, 1, r, false, 2);
                 const int i3 = (int)convs.size() - 1;
                 o1_next = add_conv(pn + ".conv1", pn + ".bn1", o3, 64, 1, 1, 1, -1, false, 4);
-                chains.push_back({i3, (int)convs.size() - 1});
+                chains.push_back({i3, (int)convs.size() - 1, ds_idx});
                 ops.push_back({OP_CHAIN, (int)chains.size() - 1});
             } else {
                 o3 = add_conv(p + ".conv3", p + ".bn3", o2, 256, 1, 1, 1, r);
             }
             release(o1), release(o2);
-            if (b == 0) release(r);
+            if (b == 0 && ds_idx < 0) release(r);
             release(x);
             x = o3;
         }
@@ -928,12 +940,19 @@ struct hrn_ctx {
                     break;
                 }
                 case OP_CHAIN: {
-                    const ConvOp &c3 = convs[chains[op.idx].first], &c1 = convs[chains[op.idx].second];
+                    const Chain &ch = chains[op.idx];
+                    const ConvOp &c3 = convs[ch.conv3], &c1 = convs[ch.conv1];
                     const Tensor &to = tensors[c3.out_t];
                     ChainArgs a;
                     a.in = row0(c3.in_t), a.res = row0(c3.res_t), a.out_y = row0(c3.out_t), a.out_t = row0(c1.out_t);
                     a.w3 = blob + c3.w_off, a.b3 = (const float *)(blob + c3.b_off);
                     a.w1 = blob + c1.w_off, a.b1 = (const float *)(blob + c1.b_off);
+                    a.x = nullptr, a.wds = nullptr, a.bds = nullptr;
+                    if (ch.ds >= 0) {
+                        const ConvOp &cd = convs[ch.ds];
+                        a.x = row0(cd.in_t), a.wds = blob + cd.w_off, a.bds = (const float *)(blob + cd.b_off);
+                        a.res = nullptr;
+                    }
                     a.m = nb * to.hpwp, a.h = to.h, a.w = to.w, a.wp = to.wp, a.hpwp = to.hpwp, a.rev = rev;
                     e = launch_bottleneck_chain(a, s);
                     break;
@@ -1175,10 +1194,12 @@ int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms
                 }
                 for (size_t k = 0; k < g.conv_idx.size(); ++k)
                     if (conv_ms && g.conv_idx[k] < conv_ms_len) conv_ms[g.conv_idx[k]] = (float)(ms * wgt[k] / tot);
-            } else if (op.kind == OP_CHAIN) {  // two 1x1 convs of equal FLOPs
-                const std::pair<int, int> &ch = h->chains[op.idx];
-                if (conv_ms && ch.first < conv_ms_len) conv_ms[ch.first] = ms * 0.5f;
-                if (conv_ms && ch.second < conv_ms_len) conv_ms[ch.second] = ms * 0.5f;
+            } else if (op.kind == OP_CHAIN) {  // two or three 1x1 convs of equal FLOPs
+                const hrn_ctx::Chain &ch = h->chains[op.idx];
+                const float share = ch.ds >= 0 ? ms / 3.f : ms * 0.5f;
+                if (conv_ms && ch.conv3 < conv_ms_len) conv_ms[ch.conv3] = share;
+                if (conv_ms && ch.conv1 < conv_ms_len) conv_ms[ch.conv1] = share;
+                if (conv_ms && ch.ds >= 0 && ch.ds < conv_ms_len) conv_ms[ch.ds] = share;
             } else if (other_ms) {
                 const int slot = op.kind == OP_STEM ? 0 : op.kind == OP_FUSE ? 1 : op.kind == OP_HEAD ? 2 : 3;
                 other_ms[slot] += ms;

@@ -59,6 +59,9 @@ struct ChainArgs {
     const float *b3;
     const void *w1;        // 64 x 256, generic fragment image with NR = 4
     const float *b1;
+    const void *x;         // block 0 only (wds != nullptr): the block input [rows][64]; the shortcut is Wds*x + bds
+    const void *wds;       // 256 x 64, generic fragment image with NR = 2, or nullptr (shortcut read from `res`)
+    const float *bds;
     int m, h, w, wp, hpwp; // rows to produce = n*hpwp; geometry for the pad mask
     int rev;
 };
