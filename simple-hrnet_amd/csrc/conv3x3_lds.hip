@@ -197,7 +197,17 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
         }
     };
     constexpr int NPIECE = NWP + SLAB_ITERS;
-    constexpr int PPC = (NPIECE + 3) / 4;  // pieces per chunk: a wave spreads its pieces over four chunks
+    // A wave spreads its LDS-DMA pieces over ALL chunks of the half-stage (at most two per chunk): bunching them (three
+    // per chunk in four chunks, the two waves of a SIMD in disjoint chunk ranges) was 2 % slower -- a wave that sits
+    // in ~450 cycles of DMA issue lets its partner run a whole chunk ahead and the pair drifts apart until the barrier.
+#ifndef HRN_C3_SPREAD
+#define HRN_C3_SPREAD CPP
+#endif
+#ifndef HRN_C3_STAGGER
+#define HRN_C3_STAGGER 0   // chunk at which waves 4-7 start issuing (waves 0-3 start at chunk 0)
+#endif
+    constexpr int SPREAD = HRN_C3_SPREAD < CPP ? HRN_C3_SPREAD : CPP;
+    constexpr int PPC = (NPIECE + SPREAD - 1) / SPREAD;  // pieces per chunk
 
     f32x4 acc[MR][NRB];
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -329,10 +339,9 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                     if (c + 1 < CPP) {
                         C3_READ_CHUNK(nxt, c + 1)
                     }
-                    // the two waves of a SIMD (w, w+4) issue their LDS-DMA pieces in different chunks
                     {
-                        const int c0 = wave < 4 ? c : c - (CPP - 4);   // waves 0-3: chunks 0..3, waves 4-7: the last four
-                        if (c0 >= 0 && c0 < 4) {
+                        const int c0 = wave < 4 ? c : c - (HRN_C3_STAGGER);   // waves 0-3: the first SPREAD chunks, waves 4-7: later ones
+                        if (c0 >= 0 && c0 < SPREAD) {
                             // (written out: as a loop hipcc spills 18 VGPRs to scratch here)
                             static_assert(PPC <= 3, "pieces per chunk");
                             if (PPC * c0 < NPIECE) piece(nx, PPC * c0);
