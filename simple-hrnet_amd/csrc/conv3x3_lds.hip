@@ -197,17 +197,20 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
         }
     };
     constexpr int NPIECE = NWP + SLAB_ITERS;
-    // A wave spreads its LDS-DMA pieces over ALL chunks of the half-stage (at most two per chunk): bunching them (three
-    // per chunk in four chunks, the two waves of a SIMD in disjoint chunk ranges) was 2 % slower -- a wave that sits
-    // in ~450 cycles of DMA issue lets its partner run a whole chunk ahead and the pair drifts apart until the barrier.
-#ifndef HRN_C3_SPREAD
-#define HRN_C3_SPREAD CPP
+    static_assert(NPIECE <= 2 * CPP, "at most two LDS-DMA pieces per chunk");
+    // LDS-DMA schedule.  A piece costs its wave ~150 issue cycles during which it issues no MFMA, so the pieces are
+    // spread thin: at most two per chunk, over every chunk of every half-stage.  (Bunching them -- three per chunk
+    // in four chunks, the two waves of a SIMD in disjoint chunk ranges -- was 2 % slower: a wave that sits in ~450
+    // cycles of DMA issue lets its partner run a whole chunk ahead and the pair drifts apart until the barrier.)
+    // Two-part slices: the weights of part 1 must go out during part 0 and those of the next part 0 during part 1
+    // (two weight buffers).  The next slab could go out any time during the stage; K0 of its pieces go behind the
+    // weights in part 0, the rest ahead of the weights in part 1.  Measured: K0 = all (12 pieces in part 0, 3 in
+    // part 1) beats the balanced 8 / 7 split by 1 % -- slab pieces issued in part 1 are still in flight at the next
+    // stage's barrier.
+#ifndef HRN_C3_K0
+#define HRN_C3_K0 SLAB_ITERS
 #endif
-#ifndef HRN_C3_STAGGER
-#define HRN_C3_STAGGER 0   // chunk at which waves 4-7 start issuing (waves 0-3 start at chunk 0)
-#endif
-    constexpr int SPREAD = HRN_C3_SPREAD < CPP ? HRN_C3_SPREAD : CPP;
-    constexpr int PPC = (NPIECE + SPREAD - 1) / SPREAD;  // pieces per chunk
+    constexpr int K0 = PARTS == 2 ? (HRN_C3_K0) : SLAB_ITERS;
 
     f32x4 acc[MR][NRB];
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -277,10 +280,11 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                         if (hf == 0) {
                             plan_w(nx, tt, s, 1, 1);
                             if (t2 < ntile) plan_s(nx, t2, s2, slab_par ^ 1);
-                            nslab = nx.ssrc ? ns_wave : 0;
+                            nslab = nx.ssrc ? (ns_wave < K0 ? ns_wave : K0) : 0;
                         } else {
                             if (t2 < ntile) plan_w(nx, t2, s2, 0, 0);
-                            npost = nx.wsrc ? nw_wave : 0;
+                            if (t2 < ntile) plan_s(nx, t2, s2, slab_par ^ 1);  // the pieces part 0 left over
+                            npost = (nx.wsrc ? nw_wave : 0) + (nx.ssrc && ns_wave > K0 ? ns_wave - K0 : 0);
                         }
                     } else if (t2 < ntile) {  // one part per slice: next slice's weights and slab together
                         plan_w(nx, t2, s2, 0, S == 1 ? 0 : (wcur ^ 1));
@@ -340,14 +344,28 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                         C3_READ_CHUNK(nxt, c + 1)
                     }
                     {
-                        const int c0 = wave < 4 ? c : c - (HRN_C3_STAGGER);   // waves 0-3: the first SPREAD chunks, waves 4-7: later ones
-                        if (c0 >= 0 && c0 < SPREAD) {
-                            // (written out: as a loop hipcc spills 18 VGPRs to scratch here)
-                            static_assert(PPC <= 3, "pieces per chunk");
-                            if (PPC * c0 < NPIECE) piece(nx, PPC * c0);
-                            if (PPC > 1 && PPC * c0 + 1 < NPIECE) piece(nx, PPC * c0 + 1);
-                            if (PPC > 2 && PPC * c0 + 2 < NPIECE) piece(nx, PPC * c0 + 2);
+                        // (calls written out: as a loop hipcc spills 18 VGPRs to scratch here)
+#define C3_ITEM(T)                                                                                     \
+    {                                                                                                  \
+        const int t_ = (T);                                                                            \
+        if (PARTS == 2 && hf == 1) {                                                                   \
+            if (t_ < SLAB_ITERS - K0)                                                                  \
+                piece(nx, NWP + K0 + t_);                                                              \
+            else if (t_ < SLAB_ITERS - K0 + NWP)                                                       \
+                piece(nx, t_ - (SLAB_ITERS - K0));                                                     \
+        } else if (t_ < (PARTS == 2 ? NWP + K0 : NPIECE)) {                                            \
+            piece(nx, t_);                                                                             \
+        }                                                                                              \
+    }
+                        const int n_items = PARTS == 2 ? (hf == 0 ? NWP + K0 : SLAB_ITERS - K0 + NWP) : NPIECE;
+                        const int extra = n_items > CPP ? n_items - CPP : 0;  // that many chunks carry two pieces
+                        if (c < extra) {
+                            C3_ITEM(2 * c)
+                            C3_ITEM(2 * c + 1)
+                        } else {
+                            C3_ITEM(c + extra)
                         }
+#undef C3_ITEM
                     }
                     if (c + 1 < CPP)
                         asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(NRB + MR) : "memory");  // chunk c landed, c+1 in flight
