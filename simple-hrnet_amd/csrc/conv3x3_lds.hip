@@ -244,7 +244,12 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                 C3_T(tA);
                 // this wave's LDS-DMA for this half-stage has landed.  vmcnt retires in order and counts stores:
                 // right after an epilogue the youngest 2*MR operations are its stores, which may stay in flight
-                if (PARTS == 2 && hf == 1) {
+                // (a single-slice problem keeps both weight halves resident after its first tile: its second half-stage
+                // waits for nothing and reads no buffer that is being refilled -- no wait, no barrier, no pipeline refill
+                // in lock-step)
+                const bool resident = PARTS == 2 && hf == 1 && S == 1 && tt > 0;
+                if (resident) {
+                } else if (PARTS == 2 && hf == 1) {
                     // the youngest `nslab` operations are the NEXT slice's slab pieces (issued during hf == 0,
                     // after this half-stage's weights): they get a second half-stage to land
                     switch (nslab) {
@@ -263,7 +268,7 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 after_epilogue = false;
-                __builtin_amdgcn_s_barrier();  // everyone's has; everyone is done reading the buffers refilled below
+                if (!resident) __builtin_amdgcn_s_barrier();  // everyone's has; everyone is done reading the buffers refilled below
                 C3_T(tB);
                 // ---- what to prefetch while this half-stage computes (issued piecewise inside the chunk loop):
                 //      hf == 0: the weights of (s, hf 1) and already the slab of the NEXT slice / tile;
