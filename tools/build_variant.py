@@ -8,7 +8,8 @@ lib_mod = importlib.import_module("simple-hrnet_amd._lib")
 for d in defs:
     lib_mod.HIPCC_FLAGS.append("-D" + d)
 lib_mod.LIB_PATH = lib_mod.LIB_PATH.replace(".so", "_%s.so" % tag)
-lib_mod.build(force=bool(os.environ.get("FORCE_BUILD")))   # the tag names the flag set: rebuilt only when sources are newer
+if not os.environ.get("NO_BUILD"):  # NO_BUILD=1: use the tagged .so as it is (e.g. one built from another commit)
+    lib_mod.build(force=bool(os.environ.get("FORCE_BUILD")))   # the tag names the flag set: rebuilt only when sources are newer
 sys.argv = ["bench.py"] + sys.argv[3:]
 sys.path.insert(0, ROOT)
 import runpy
