@@ -295,3 +295,40 @@ def test_bf16_head_mfma_vs_fp32_weight_head(pkg, monkeypatch):
     np.testing.assert_array_equal(pts_a.cpu().numpy()[..., :2], ref[..., :2])
     assert idx.shape == (n, 17)
     a.close(), b.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_other_joint_count_and_two_engines_on_side_streams(pkg, dtype):
+    """MPII-style 16 joints (the head pads joints to two MFMA fragments), two engines alive at once, each driven
+    from its own non-default stream: results must equal the oracle (fp32) / the fp32 engine within the bf16 bound."""
+    T = _oracle()
+    c, h, w, n, joints = 32, 128, 96, 3, 16
+    sd_np = pkg.synth_state_dict(c, joints, 9)
+    crops = torch.from_numpy(pkg.synth_crops(n, h, w, seed=41)).cuda()
+    boxes = pkg.synth_boxes(n, seed=42)
+    ref_hm, ref_pts = T.predict_crops(pkg.synth.to_torch_state_dict(sd_np), crops.cpu(), boxes)
+    a = pkg.NativeHRNet(c, joints, (h, w), dtype, max_batch=2, device=0).load_state_dict(sd_np)
+    b = pkg.NativeHRNet(c, joints, (h, w), dtype, max_batch=4, device=0).load_state_dict(sd_np)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):  # interleave the two engines on two streams
+        with torch.cuda.stream(sa):
+            ha, pa = a.predict_crops(crops, boxes, return_heatmaps=True)
+        with torch.cuda.stream(sb):
+            hb, pb = b.predict_crops(crops, boxes, return_heatmaps=True)
+        outs.append((ha, pa, hb, pb))
+    torch.cuda.synchronize()
+    for ha, pa, hb, pb in outs:
+        assert tuple(ha.shape) == (n, joints, h // 4, w // 4) and tuple(pa.shape) == (n, joints, 3)
+        assert torch.equal(ha, hb) and torch.equal(pa, pb)          # micro-batch 2 vs 4, stream a vs b
+        assert torch.equal(ha, outs[0][0]) and torch.equal(pa, outs[0][1])
+    hm, pts = outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy()
+    if dtype == "fp32":
+        np.testing.assert_allclose(hm, ref_hm, rtol=0, atol=HM_ATOL_F32)
+        np.testing.assert_array_equal(pts[..., :2], ref_pts[..., :2])
+    else:
+        err = np.abs(hm - ref_hm).max()
+        assert err < 0.05 * ref_hm.std() + 0.05, err
+        np.testing.assert_array_equal(pts[..., :2], T.decode_heatmaps(hm, boxes)[..., :2])
+    a.close(), b.close()
