@@ -10,6 +10,8 @@
 //       8 stores (the S = TH/2 branch of the real kernel without its LDS-DMA)
 //   V6  V5 + LDS-DMA: 12 pieces per wave in even half-stages, 3 in odd ones, two per chunk
 //   V7  V0 + that LDS-DMA only
+//   V10 V7's bytes through registers instead: global_load_dwordx4 now, ds_write_b128 three chunks later
+//   V8  V7 with the LDS-DMA issued by waves 0-3 only (twice as many each); V9: by waves 0-3 in even chunks, 4-7 in odd
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(512, 2) void loop_kernel(float *out, int halves, co
     if (V == 4 && wave >= 4) __builtin_amdgcn_s_sleep(2);
     u32x4 rp4[MR];
     u32x2 rp2[MR];
+    u32x4 stg[6];
     const size_t span = gbytes / gridDim.x;   // this block's private slice of the big buffers
     const GAS char *bsrc = (const GAS char *)gsrc + (size_t)blockIdx.x * span;
     GAS char *bdst = (GAS char *)gdst + (size_t)blockIdx.x * span;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(512, 2) void loop_kernel(float *out, int halves, co
         if (V >= 5) {
             __builtin_amdgcn_s_barrier();
             const bool last = (h % TH) == TH - 1;
-            if (V != 7 && last) {  // residual request: lands under this half-stage's MFMAs
+            if (V < 7 && last) {  // residual request: lands under this half-stage's MFMAs
 #pragma unroll
                 for (int i = 0; i < MR; ++i) {
                     const GAS char *rp = bsrc + (roff + (size_t)(wave * 64 + i * 16 + li) * 96 + g * 24) % (span - 4096);
@@ -85,7 +88,36 @@ __global__ __launch_bounds__(512, 2) void loop_kernel(float *out, int halves, co
 #pragma unroll
             for (int c = 0; c < CPP; ++c) {
                 if (c + 1 < CPP) { RD_W((c + 1) & 1, c + 1) RD_X((c + 1) & 1, c + 1) }
-                if (V >= 6) {  // LDS-DMA pieces: 12 per wave in even half-stages (two per chunk), 3 in odd ones
+                if (V == 10) {
+                    const int np = (h & 1) ? 3 : 12;
+                    // write what was loaded three chunks ago (ring of 3 x 2 registers), then load this chunk's two
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int slot = (c % 3) * 2 + t;
+                        if (c >= 3 && 2 * (c - 3) + t < np) {
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(5 - t) : "memory");
+                            asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + 100 * 1024 + ((2 * (c - 3) + t) * 8 + wave) * 1024 % (48 * 1024) + lane * 16), "v"(stg[slot]) : "memory");
+                        }
+                        if (2 * c + t < np) {
+                            const GAS char *sp = bsrc + (doff + (size_t)(wave * 64 + lane) * 16) % (span - 4096);
+                            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg[slot]) : "v"(sp));
+                            doff += 8192;
+                        }
+                    }
+                } else if (V == 8 || V == 9) {
+                    const int np = (h & 1) ? 6 : 24;
+                    const bool mine = V == 8 ? wave < 4 : ((c & 1) == 0) == (wave < 4);
+                    const int per = V == 8 ? 4 : 7;  // V9: a wave issues in every other chunk: up to 7 there
+                    const int first = V == 8 ? 4 * c : (c >> 1) * 7;
+                    if (mine) {
+#pragma unroll
+                        for (int t = 0; t < per; ++t)
+                            if (first + t < np) {
+                                glds16(bsrc + (doff + (size_t)(wave * 64 + lane) * 16) % (span - 4096), smem + 100 * 1024 + ((first + t) * 8 + wave) * 1024 % (48 * 1024));
+                                doff += 8192;
+                            }
+                    }
+                } else if (V >= 6) {  // LDS-DMA pieces: 12 per wave in even half-stages (two per chunk), 3 in odd ones
                     const int np = (h & 1) ? 3 : 12;
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
@@ -100,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void loop_kernel(float *out, int halves, co
                 MMA(c & 1)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (V != 7 && last) {  // epilogue
+            if (V < 7 && last) {  // epilogue
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < MR; ++i) {
@@ -222,6 +254,9 @@ int main() {
     run<5, 2>("V5 + epilogue every 2 halves (S=1)", 7, 1, 1);
     run<5, 4>("V5 + epilogue every 4 halves (S=2)", 7, 1, 1);
     run<7, 2>("V7 + LDS-DMA only (12 / 3 pieces per wave)", 7, 1, 1);
+    run<10, 2>("V10 same bytes via registers + ds_write", 7, 1, 1);
+    run<8, 2>("V8 LDS-DMA by waves 0-3 only (24 / 6)", 7, 1, 1);
+    run<9, 2>("V9 LDS-DMA alternating halves per chunk", 7, 1, 1);
     run<6, 4>("V6 + epilogue/4 + LDS-DMA", 7, 1, 1);
     return 0;
 }
