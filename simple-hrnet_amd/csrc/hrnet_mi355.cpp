@@ -73,6 +73,7 @@ struct DirectGroup {
     std::vector<int2> map_host;
     int cached_nb = -1;
     int nblocks = 0;
+    int mr = 4;  // 16-pixel fragments per wave of the current map (4, 2 or 1)
 };
 
 struct FuseOp {
@@ -594,7 +595,7 @@ struct hrn_ctx {
     // of the class with the M tile varying fastest: block id b runs on XCD b % 8, so all readers of one input tile
     // are 8 ids apart = on one XCD, back to back, and the tile comes from HBM once.  Rounds are padded to 8 entries
     // (an out-of-range M tile returns at once) to keep that alignment.  Classes go out costliest first.
-    int direct_group_blocks(const DirectGroup &g, int nb, std::vector<int2> *out) const {
+    int direct_group_blocks(const DirectGroup &g, int nb, std::vector<int2> *out, int mr = 4) const {
         struct Cls {
             int in_t, k, stride;
             std::vector<int> members;
@@ -614,7 +615,7 @@ struct hrn_ctx {
         int n = 0;
         if (out) out->clear();
         for (const Cls &cl : cls) {
-            const int mtiles = (nb * tensors[convs[g.conv_idx[cl.members[0]]].out_t].hpwp + 255) / 256;
+            const int mtiles = (nb * tensors[convs[g.conv_idx[cl.members[0]]].out_t].hpwp + 64 * mr - 1) / (64 * mr);
             for (int round = 0; round * 8 < mtiles; ++round)
                 for (int k : cl.members) {
                     const int ngroups = convs[g.conv_idx[k]].cout / (16 * g.nr);
@@ -628,7 +629,8 @@ struct hrn_ctx {
 
     bool setup_dgroups() {
         for (auto &g : dgroups) {
-            g.map_capacity = direct_group_blocks(g, max_batch, nullptr);
+            // M tiles shrink (mr 4 -> 2 -> 1) only while a launch has fewer than 512 blocks: 4x that bounds every case
+            g.map_capacity = std::max<int64_t>(direct_group_blocks(g, max_batch, nullptr), 4 * 512 + 64 * (int64_t)g.conv_idx.size() * 8);
             if (!hip_ok(hipMalloc((void **)&g.map_dev, (size_t)g.map_capacity * sizeof(int2)), "hipMalloc(blockmap)"))
                 return false;
             if (!hip_ok(hipMalloc((void **)&g.args_dev, g.conv_idx.size() * sizeof(ConvArgs)), "hipMalloc(conv args)"))
@@ -927,7 +929,9 @@ struct hrn_ctx {
                     if (g.cached_nb != nb) {  // descriptors (row counts) and block map depend on the micro-batch size
                         g.args_host.clear();
                         for (int ci : g.conv_idx) g.args_host.push_back(conv_args(convs[ci], nb, rev));
-                        g.nblocks = direct_group_blocks(g, nb, &g.map_host);
+                        g.mr = 4;  // shorter M tiles for small launches: fill the chip, shorten the serial K loop per block
+                        while (g.mr > 1 && direct_group_blocks(g, nb, nullptr, g.mr) < 512) g.mr >>= 1;
+                        g.nblocks = direct_group_blocks(g, nb, &g.map_host, g.mr);
                         e = hipMemcpyAsync(g.args_dev, g.args_host.data(), g.args_host.size() * sizeof(ConvArgs),
                                            hipMemcpyHostToDevice, s);
                         if (e != hipSuccess) break;
@@ -936,7 +940,7 @@ struct hrn_ctx {
                         if (e != hipSuccess) break;
                         g.cached_nb = nb;
                     }
-                    e = launch_conv_group(dtype, g.args_dev, g.map_dev, g.nblocks, g.nr, s);
+                    e = launch_conv_group(dtype, g.args_dev, g.map_dev, g.nblocks, g.nr, g.mr, s);
                     break;
                 }
                 case OP_CHAIN: {

@@ -113,7 +113,7 @@ struct DecodeArgs {        // SimpleHRNet.py:297-308
 
 hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s);
 // grouped launch of the generic kernel: device-resident ConvArgs[], block map entries (prob | cout tile << 8, M tile)
-hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr,
+hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr, int mr,
                              hipStream_t s);
 hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb, int ks,
                               int nrb, hipStream_t s);

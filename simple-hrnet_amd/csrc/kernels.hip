@@ -239,24 +239,30 @@ __global__ __launch_bounds__(256) void conv_direct_group_kernel(const ConvArgs *
 }
 
 template <int DT, int NR>
-static hipError_t launch_conv_group_t(const ConvArgs *probs, const int2 *map, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 4>), dim3(nblocks), dim3(256), 0, s, probs, map);
+static hipError_t launch_conv_group_t(const ConvArgs *probs, const int2 *map, int nblocks, int mr, hipStream_t s) {
+    if (mr == 1)
+        hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 1>), dim3(nblocks), dim3(256), 0, s, probs, map);
+    else if (mr == 2)
+        hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 2>), dim3(nblocks), dim3(256), 0, s, probs, map);
+    else
+        hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 4>), dim3(nblocks), dim3(256), 0, s, probs, map);
     return hipGetLastError();
 }
 
-hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr,
+// mr = 16-pixel fragments per wave (4, 2 or 1): the host shrinks the M tile when a launch would not fill the chip
+hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr, int mr,
                              hipStream_t s) {
     if (nblocks <= 0) return hipSuccess;
     const int2 *map = (const int2 *)map_dev;
     if (dtype == DT_BF16) {
-        if (nr == 6) return launch_conv_group_t<DT_BF16, 6>(probs_dev, map, nblocks, s);
-        if (nr == 4) return launch_conv_group_t<DT_BF16, 4>(probs_dev, map, nblocks, s);
-        if (nr == 3) return launch_conv_group_t<DT_BF16, 3>(probs_dev, map, nblocks, s);
-        if (nr == 2) return launch_conv_group_t<DT_BF16, 2>(probs_dev, map, nblocks, s);
+        if (nr == 6) return launch_conv_group_t<DT_BF16, 6>(probs_dev, map, nblocks, mr, s);
+        if (nr == 4) return launch_conv_group_t<DT_BF16, 4>(probs_dev, map, nblocks, mr, s);
+        if (nr == 3) return launch_conv_group_t<DT_BF16, 3>(probs_dev, map, nblocks, mr, s);
+        if (nr == 2) return launch_conv_group_t<DT_BF16, 2>(probs_dev, map, nblocks, mr, s);
     } else {
-        if (nr == 4) return launch_conv_group_t<DT_F32, 4>(probs_dev, map, nblocks, s);
-        if (nr == 3) return launch_conv_group_t<DT_F32, 3>(probs_dev, map, nblocks, s);
-        if (nr == 2) return launch_conv_group_t<DT_F32, 2>(probs_dev, map, nblocks, s);
+        if (nr == 4) return launch_conv_group_t<DT_F32, 4>(probs_dev, map, nblocks, mr, s);
+        if (nr == 3) return launch_conv_group_t<DT_F32, 3>(probs_dev, map, nblocks, mr, s);
+        if (nr == 2) return launch_conv_group_t<DT_F32, 2>(probs_dev, map, nblocks, mr, s);
     }
     return hipErrorInvalidValue;
 }
@@ -277,6 +283,11 @@ static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
         if (a.res && a.ksize == 1 && pre_mode == 2) return launch_conv_tt<DT, NR, 2, true>(a, s);
         if (a.res && a.ksize == 1 && pre_mode == 3) return launch_conv_tt<DT, NR, 2, false>(a, s);
     }
+    // small launches (few crops): shorter M tiles, so that the chip fills and a block's serial K loop shrinks with it
+    const int ngroups = a.cout / (16 * NR);
+    const long blocks4 = (long)((a.m + 255) / 256) * ngroups;
+    if (blocks4 < 256) return launch_conv_tt<DT, NR, 1, false>(a, s);
+    if (blocks4 < 512) return launch_conv_tt<DT, NR, 2, false>(a, s);
     return launch_conv_tt<DT, NR, 4, false>(a, s);
 }
 
