@@ -472,13 +472,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem 
     // block map entry: x = problem | cout tile << 8 | M tiles of this block << 16,  y = first M tile
     const Conv3Problem p = probs[bm.x & 0xff];
     const int nt = (bm.x >> 8) & 0xff, tiles = bm.x >> 16;
-    if constexpr (NRB == 4) {  // 64 accumulator + 64 fragment registers at MR = 4 would spill: 384-pixel tiles only
-        conv3_run<CFG, 3>(p, nt, bm.y, tiles, nb, smem);
+    // y = first M tile | small << 30.  small: 128-pixel tiles (MR = 1) -- the host asks for them when even one tile
+    // per block would leave CUs idle (a few crops): four times the blocks, a quarter of the MFMAs on a block's serial path
+    const int mt0 = bm.y & 0x3fffffff;
+    if (bm.y >> 30) {
+        conv3_run<CFG, 1>(p, nt, mt0, tiles, nb, smem);
+    } else if constexpr (NRB == 4) {  // 64 accumulator + 64 fragment registers at MR = 4 would spill: 384-pixel tiles only
+        conv3_run<CFG, 3>(p, nt, mt0, tiles, nb, smem);
     } else {
         if (p.bm == 512)
-            conv3_run<CFG, 4>(p, nt, bm.y, tiles, nb, smem);
+            conv3_run<CFG, 4>(p, nt, mt0, tiles, nb, smem);
         else
-            conv3_run<CFG, 3>(p, nt, bm.y, tiles, nb, smem);  // bm == 384
+            conv3_run<CFG, 3>(p, nt, mt0, tiles, nb, smem);  // bm == 384
     }
 }
 

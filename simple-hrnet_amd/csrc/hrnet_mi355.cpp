@@ -136,6 +136,8 @@ struct hrn_ctx {
     bool disable_group = getenv("HRN_DISABLE_GROUP") != nullptr;
     bool disable_dgroup = getenv("HRN_DISABLE_DGROUP") != nullptr;
     bool disable_chain = getenv("HRN_DISABLE_CHAIN") != nullptr;
+    bool small_tiles = getenv("HRN_SMALL_TILES") ? atoi(getenv("HRN_SMALL_TILES")) != 0 : true;
+    int small_below = getenv("HRN_SMALL_BELOW") ? atoi(getenv("HRN_SMALL_BELOW")) : 384;
     bool disable_chain_ds = getenv("HRN_DISABLE_CHAIN_DS") != nullptr;
     // 1: convolutions that read the same tensor share one cout-tile width so that they can share a launch (and L2)
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
@@ -511,12 +513,21 @@ struct hrn_ctx {
         std::vector<Ent> ents;
         // Block lengths follow the size of the launch: small batches get shorter blocks (at least ~2 per CU before
         // anything else), and long blocks are only worth it when there are many blocks per CU to begin with.
+        // a few crops: even one tile per block leaves CUs idle -> 128-pixel tiles for the whole launch
+        long one_per_block = 0;
+        for (int ci : g.conv_idx) {
+            const ConvOp &cv = convs[ci];
+            const Tensor &to = tensors[cv.out_t];
+            const int bmn = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+            one_per_block += (long)((nb * to.hpwp + bmn - 1) / bmn) * cv.ntiles;
+        }
+        const bool small = small_tiles && one_per_block < small_below;
         auto count_blocks = [&](int div) {
             long total = 0;
             for (int ci : g.conv_idx) {
                 const ConvOp &cv = convs[ci];
                 const Tensor &to = tensors[cv.out_t];
-                const int bm = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+                const int bm = small ? 128 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
                 const int mtiles = (nb * to.hpwp + bm - 1) / bm;
                 const int tpb = std::max(1, conv3_tiles_per_block(cv) / div);
                 total += (long)((mtiles + tpb - 1) / tpb) * cv.ntiles;
@@ -530,7 +541,7 @@ struct hrn_ctx {
         for (size_t k = 0; k < g.conv_idx.size(); ++k) {
             const ConvOp &cv = convs[g.conv_idx[k]];
             const Tensor &to = tensors[cv.out_t];
-            const int bm = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+            const int bm = small ? 128 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
             const int mtiles = (nb * to.hpwp + bm - 1) / bm;
             // Blocks come in two lengths: long ones (fewer pipeline prologues -- a block's first loads have nothing to
             // hide behind) over the first `long_share` of the M tiles, short ones over the rest to fill the tail.
@@ -563,7 +574,7 @@ struct hrn_ctx {
                             // every other launch walks the tensors backwards: a launch starts on what its producer
                             // wrote last, i.e. on the part most likely still in the Infinity Cache
                             if (reverse) mt0 = mtiles - mt0 - tiles;
-                            ents.push_back({key, int2{(int)k | (nt << 8) | (tiles << 16), mt0}});
+                            ents.push_back({key, int2{(int)k | (nt << 8) | (tiles << 16), mt0 | (small ? 1 << 30 : 0)}});
                         }
             }
         }
@@ -665,7 +676,7 @@ struct hrn_ctx {
                 fast_div(to.wp, &q.magic_wp, &q.shift_wp);
                 if (to.wp > g.max_wp) g.max_wp = to.wp;
             }
-            g.map_capacity = 64;  // one M tile per block = most blocks any split can produce
+            g.map_capacity = 64 + 4 * (int64_t)std::max(small_below, 256) + 1024;  // one M tile per block = most blocks any split can produce (+ the small-tile mode)
             for (int ci : g.conv_idx) {
                 const ConvOp &cv = convs[ci];
                 const Tensor &to = tensors[cv.out_t];
