@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-prepath", action="store_true", help="skip the crop pre-path side measurement")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -107,6 +108,44 @@ def cpu_baseline(c, h, w, budget_s):
     except Exception as e:  # timeout or failure: report it, never block the GPU number
         return {"value": None, "unit": "crops/s", "cores": os.cpu_count(), "kind": "port",
                 "sample": "cpu baseline did not finish: %s" % type(e).__name__}
+
+
+def prepath_measure(pkg, net, dev):
+    """Side measurement (not part of `value`): the crop pre-path of SimpleHRNet.py:236-278 on a synthetic 1080p frame
+    with 16 people -- GPU kernel (frame resident in HBM) vs the reference's PIL transform on one host core, same boxes."""
+    import numpy as np
+    import torch
+    from oracle import prepath_oracle as P
+
+    rng = np.random.default_rng(5)
+    hf, wf, people = 1080, 1920, 16
+    frame = rng.integers(0, 256, (hf, wf, 3), dtype=np.uint8)
+    dets = np.zeros((people, 4), np.float32)
+    for i in range(people):
+        bh = rng.integers(300, 900)
+        bw = int(bh * rng.uniform(0.3, 0.6))
+        x1, y1 = rng.uniform(0, wf - bw), rng.uniform(0, hf - bh)
+        dets[i] = (x1, y1, x1 + bw, y1 + bh)
+    fdev = torch.from_numpy(frame).to(dev)
+    for _ in range(3):
+        images, boxes, _ = net.preprocess_frame(fdev, dets)
+    torch.cuda.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        net.preprocess_frame(fdev, dets)
+    torch.cuda.synchronize()
+    gpu = reps * people / (time.perf_counter() - t0)
+    h, w = net.resolution
+    try:
+        t0 = time.perf_counter()
+        ref_images, ref_boxes = P.prepath(frame, dets, h, w, resize=P.pil_resize)
+        cpu = people / (time.perf_counter() - t0)
+        same = bool(np.array_equal(images.cpu().numpy(), ref_images) and np.array_equal(boxes, ref_boxes))
+    except Exception:  # Pillow missing
+        cpu, same = None, None
+    return {"crops_per_s": round(gpu, 1), "unit": "crops/s", "workload": "1920x1080 uint8 frame resident in HBM, 16 people, crop+pad+resize+normalise to %dx%d" % (h, w),
+            "cpu_pil_crops_per_s": None if cpu is None else round(cpu, 1), "cpu_cores": 1, "bit_identical_to_pil_path": same}
 
 
 def main():
@@ -228,6 +267,8 @@ def main():
                 "subset_share_of_pass_time": round(sub_ms / all_ms, 3),
                 "pass_ms": {"convs": round(sum(conv_ms), 3), **{k: round(v, 3) for k, v in other.items()}},
             }
+        if world == 1 and not a.no_prepath:
+            out["prepath"] = prepath_measure(pkg, net, dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.c, a.height, a.width, a.cpu_seconds)
     if dist:

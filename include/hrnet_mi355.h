@@ -93,6 +93,20 @@ int hrn_weight_blob_read(hrn_handle h, int64_t offset, void *dst_host, int64_t n
 int hrn_forward(hrn_handle h, const void *images_dev, int n, const void *boxes_dev, int box_dtype, float *pts_dev,
                 float *heatmaps_dev, void *stream);
 
+/* Crop pre-path of the single-image multi-person branch (SimpleHRNet.py:236-278): for each
+ * detector box -- round, correct the aspect ratio by padding (:243-272), slice the BGR frame as RGB (:274), zero-pad
+ * (:276), Resize((H,W)) with Pillow's antialiased bilinear filter, ToTensor, Normalize (:167-172) -- written straight
+ * into the (n,3,H,W) fp32 batch hrn_forward reads.  Bit-identical to the reference's transform.
+ *   frame_dev   (frame_h, frame_w, 3) uint8 BGR, device
+ *   dets_host   (n, det_stride) float32 on the HOST, columns 0..3 = x1,y1,x2,y2 as the detector returns them
+ *   images_dev  out: (n,3,H,W) float32, device
+ *   boxes_host  out: (n,4) int32 [x1,y1,x2,y2] = the padded boxes the decode scales by (may be NULL)
+ *   boxes_dev   out: the same on the device, ready for hrn_forward(..., HRN_BOX_I32, ...) (may be NULL)
+ * Boxes must lie inside the frame after rounding (the detector wrappers clamp them: YOLOv3.py:49-56) and be
+ * non-degenerate; otherwise the call fails (the reference would wrap around / divide by zero). */
+int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, int frame_w, const float *dets_host,
+                         int det_stride, int n, float *images_dev, int32_t *boxes_host, int32_t *boxes_dev, void *stream);
+
 /* Introspection used by tests, bench.py and the roofline accounting. */
 int hrn_conv_count(hrn_handle h);
 int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out);

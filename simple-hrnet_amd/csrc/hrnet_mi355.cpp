@@ -153,6 +153,11 @@ struct hrn_ctx {
     int head_slabs = 1, head_slab_px = 1024;
     float *part_val = nullptr;
     int *part_idx = nullptr;
+    // crop pre-path scratch (grown on demand, never inside hrn_forward)
+    unsigned char *pre_tmp = nullptr;
+    size_t pre_tmp_bytes = 0;
+    CropParams *pre_params = nullptr;
+    int pre_params_cap = 0;
     int64_t workspace_bytes = 0;
 
     // ---------------------------------------------------------------- planning
@@ -700,6 +705,8 @@ struct hrn_ctx {
             for (auto &b : buffers)
                 if (b.dev) (void)hipFree(b.dev);
             if (blob) (void)hipFree(blob);
+            if (pre_tmp) (void)hipFree(pre_tmp);
+            if (pre_params) (void)hipFree(pre_params);
             if (part_val) (void)hipFree(part_val);
             if (part_idx) (void)hipFree(part_idx);
             if (probs_dev) (void)hipFree(probs_dev);
@@ -1139,6 +1146,87 @@ int hrn_forward(hrn_handle h, const void *images_dev, int n, const void *boxes_d
         float *hp = heatmaps_dev ? heatmaps_dev + (size_t)off * h->joints * hm : nullptr;
         if (!h->run_pass(img, nb, bx, box_dtype, p, hp, (hipStream_t)stream, nullptr)) return 8;
     }
+    return 0;
+}
+
+// SimpleHRNet.py:236-278.  The box arithmetic is Python's, restated in double: round() is round-half-even on a
+// float, `//` on non-negative ints is C's `/`, int(round(x)) = nearbyint under the default rounding mode.
+int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, int frame_w, const float *dets_host,
+                         int det_stride, int n, float *images_dev, int32_t *boxes_host, int32_t *boxes_dev, void *stream) {
+    if (!h) return 1;
+    if (h->plan_only) {
+        h->err = "plan-only handle (device_id < 0): there is no CPU compute path";
+        return 7;
+    }
+    if (n < 0 || det_stride < 4 || frame_h <= 0 || frame_w <= 0 || (n > 0 && (!frame_dev || !dets_host || !images_dev))) {
+        h->err = "bad frame / detections / n";
+        return 7;
+    }
+    if (n == 0) return 0;
+    if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return 6;
+    const int H = h->H, W = h->W;
+    std::vector<CropParams> cps(n);
+    std::vector<int32_t> boxes((size_t)n * 4);
+    size_t tmp_bytes = 0;
+    int max_h_pad = 0;
+    for (int i = 0; i < n; ++i) {
+        const float *d = dets_host + (size_t)i * det_stride;
+        const long x1 = (long)std::nearbyint((double)d[0]), y1 = (long)std::nearbyint((double)d[1]);
+        const long x2 = (long)std::nearbyint((double)d[2]), y2 = (long)std::nearbyint((double)d[3]);
+        if (x1 < 0 || y1 < 0 || x2 <= x1 || y2 <= y1 || x1 >= frame_w || y1 >= frame_h) {
+            h->err = "detection " + std::to_string(i) + " is degenerate or outside the frame";
+            return 7;
+        }
+        const double cf = (double)H / (double)W * (double)(x2 - x1) / (double)(y2 - y1);
+        long x1n = x1, x2n = x2, y1n = y1, y2n = y2, pt = 0, pb = 0, pl = 0, pr = 0;
+        if (cf > 1) {  // increase y side
+            const long center = y1 + (y2 - y1) / 2;
+            const long length = (long)std::nearbyint((double)(y2 - y1) * cf);
+            y1n = center - length / 2, y2n = center + length / 2;
+            pt = std::labs(y1n - y1), pb = std::labs(y2n - y2);
+        } else if (cf < 1) {
+            const long center = x1 + (x2 - x1) / 2;
+            const long length = (long)std::nearbyint((double)(x2 - x1) * 1 / cf);
+            x1n = center - length / 2, x2n = center + length / 2;
+            pl = std::labs(x1n - x1), pr = std::labs(x2n - x2);
+        }
+        CropParams &cp = cps[i];
+        cp.x1 = (int)x1, cp.y1 = (int)y1;
+        cp.w_crop = (int)(std::min<long>(x2, frame_w) - x1), cp.h_crop = (int)(std::min<long>(y2, frame_h) - y1);  // numpy slicing
+        cp.pad_top = (int)pt, cp.pad_left = (int)pl;
+        cp.h_pad = cp.h_crop + (int)(pt + pb), cp.w_pad = cp.w_crop + (int)(pl + pr);
+        cp.tmp_off = (long long)tmp_bytes;
+        tmp_bytes += ((size_t)cp.h_pad * W * 3 + 255) / 256 * 256;
+        if (cp.h_pad > max_h_pad) max_h_pad = cp.h_pad;
+        boxes[(size_t)i * 4 + 0] = (int32_t)x1n, boxes[(size_t)i * 4 + 1] = (int32_t)y1n;
+        boxes[(size_t)i * 4 + 2] = (int32_t)x2n, boxes[(size_t)i * 4 + 3] = (int32_t)y2n;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (tmp_bytes > h->pre_tmp_bytes || n > h->pre_params_cap) {  // grow the scratch: wait for whoever still reads the old one
+        if (!h->hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return 6;
+        if (tmp_bytes > h->pre_tmp_bytes) {
+            if (h->pre_tmp) (void)hipFree(h->pre_tmp);
+            h->pre_tmp = nullptr, h->pre_tmp_bytes = 0;
+            if (!h->hip_ok(hipMalloc((void **)&h->pre_tmp, tmp_bytes), "hipMalloc(pre-path scratch)")) return 6;
+            h->pre_tmp_bytes = tmp_bytes;
+        }
+        if (n > h->pre_params_cap) {
+            if (h->pre_params) (void)hipFree(h->pre_params);
+            h->pre_params = nullptr, h->pre_params_cap = 0;
+            if (!h->hip_ok(hipMalloc((void **)&h->pre_params, (size_t)n * sizeof(CropParams)), "hipMalloc(crop params)")) return 6;
+            h->pre_params_cap = n;
+        }
+    }
+    if (!h->hip_ok(hipMemcpyAsync(h->pre_params, cps.data(), (size_t)n * sizeof(CropParams), hipMemcpyHostToDevice, s),
+                   "hipMemcpyAsync(crop params)"))
+        return 6;
+    if (boxes_dev && !h->hip_ok(hipMemcpyAsync(boxes_dev, boxes.data(), boxes.size() * 4, hipMemcpyHostToDevice, s),
+                                "hipMemcpyAsync(boxes)"))
+        return 6;
+    if (boxes_host) memcpy(boxes_host, boxes.data(), boxes.size() * 4);
+    if (!h->hip_ok(launch_prepath(frame_dev, frame_w, h->pre_params, n, max_h_pad, h->pre_tmp, images_dev, H, W, s),
+                   "pre-path launch"))
+        return 8;
     return 0;
 }
 

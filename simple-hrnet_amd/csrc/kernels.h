@@ -77,6 +77,16 @@ struct StemArgs {          // conv1 3->64 3x3 s2 + BN + ReLU, NCHW fp32 in, flat
     int out_h, out_w, out_wp, out_hpwp;
 };
 
+// Crop pre-path (prepath.hip): one person's slice of the frame, its zero padding and where its horizontal pass lives
+struct CropParams {
+    int x1, y1, w_crop, h_crop;   // slice of the frame that is actually read (numpy clamps the stop index)
+    int pad_top, pad_left;        // zero rows / columns in front of it (np.pad)
+    int h_pad, w_pad;             // size of the padded crop = input of the resize
+    long long tmp_off;            // byte offset of this crop's [h_pad][W][3] uint8 intermediate
+};
+hipError_t launch_prepath(const unsigned char *frame_dev, int frame_w, const CropParams *crops_dev, int n, int max_h_pad,
+                          unsigned char *tmp_dev, float *images_dev, int H, int W, hipStream_t s);
+
 struct FuseTerm {
     const void *ptr;
     int shift;      // nearest-upsample factor 2^shift (0 = same resolution)

@@ -198,6 +198,44 @@ class NativeHRNet:
         return (hm, pts) if return_heatmaps else pts
 
     # -- introspection --------------------------------------------------------------------------
+    def preprocess_frame(self, frame: torch.Tensor, detections) -> Tuple[torch.Tensor, np.ndarray, torch.Tensor]:
+        """The crop pre-path of ``SimpleHRNet.predict`` for one frame (``SimpleHRNet.py:236-278``) on the GPU.
+
+        ``frame``: (Hf, Wf, 3) uint8 BGR (the cv2 frame; host tensors / arrays are uploaded once);
+        ``detections``: (P, >=4) float array-like, columns 0..3 = x1, y1, x2, y2 as the detector returns them.
+        Returns ``(images (P,3,H,W) float32 on the GPU, boxes (P,4) int32 numpy, boxes on the GPU)`` -- bit-identical
+        to the reference's ``ToPILImage -> Resize -> ToTensor -> Normalize`` of the padded RGB crops."""
+        if not isinstance(frame, torch.Tensor):
+            frame = torch.from_numpy(np.ascontiguousarray(frame))
+        if frame.dtype != torch.uint8 or frame.dim() != 3 or frame.shape[2] != 3:
+            raise ValueError("frame must be (H, W, 3) uint8 BGR")
+        frame = frame.to(self.torch_device, non_blocking=True).contiguous()
+        dets = np.ascontiguousarray(np.asarray(detections.cpu() if isinstance(detections, torch.Tensor) else detections,
+                                               dtype=np.float32))
+        if dets.ndim != 2 or (len(dets) and dets.shape[1] < 4):
+            raise ValueError("detections must be (P, >=4)")
+        p = len(dets)
+        h, w = self.resolution
+        images = torch.empty((p, 3, h, w), dtype=torch.float32, device=self.torch_device)
+        boxes = np.empty((p, 4), dtype=np.int32)
+        boxes_dev = torch.empty((p, 4), dtype=torch.int32, device=self.torch_device)
+        if p:
+            with torch.cuda.device(self.device_index):
+                rc = self._lib.hrn_preprocess_frame(self._h, frame.data_ptr(), int(frame.shape[0]), int(frame.shape[1]),
+                                                    dets.ctypes.data, int(dets.shape[1]), p, images.data_ptr(),
+                                                    boxes.ctypes.data, boxes_dev.data_ptr(), self._stream())
+            self._check(rc, "hrn_preprocess_frame")
+        return images, boxes, boxes_dev
+
+    def predict_frame(self, frame, detections, return_heatmaps: bool = False):
+        """pre-path + model + decode for one frame: what ``SimpleHRNet._predict_single`` does after the detector.
+        Returns ``(boxes (P,4) int32 numpy, pts (P,J,3) on the GPU[, heatmaps])``."""
+        images, boxes, boxes_dev = self.preprocess_frame(frame, detections)
+        out = self.predict_crops(images, boxes_dev, return_heatmaps=return_heatmaps)
+        if return_heatmaps:
+            return boxes, out[1], out[0]
+        return boxes, out
+
     def conv_infos(self) -> List[_lib.ConvInfo]:
         out = []
         for i in range(self._lib.hrn_conv_count(self._h)):

@@ -1,0 +1,117 @@
+"""Crop pre-path (SimpleHRNet.py:236-278).
+
+CPU: the numpy restatement of Pillow's resampler against the real ``PIL.Image.resize`` (bit-exact), the box
+arithmetic, the committed fixture.  GPU: ``hrn_preprocess_frame`` against the oracle / the fixture, bit-exact, and the
+whole frame -> joints chain."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, load_pkg, state_dict_np
+from oracle import prepath_oracle as P
+
+SHAPES = [(37, 29, 16, 12), (200, 150, 128, 96), (64, 48, 64, 48), (50, 300, 64, 48), (411, 123, 64, 48),
+          (64, 48, 128, 96), (97, 288, 384, 288), (1000, 20, 32, 24), (33, 97, 96, 64), (17, 48, 64, 48)]
+
+
+@pytest.mark.parametrize("h,w,oh,ow", SHAPES)
+def test_resampler_restatement_equals_pillow(h, w, oh, ow):
+    PIL = pytest.importorskip("PIL")
+    img = np.random.default_rng(h * 1000 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(P.pil_bilinear_u8(img, oh, ow), P.pil_resize(img, oh, ow))
+
+
+def test_box_arithmetic():
+    # 384x288: target aspect h/w = 4/3
+    # tall enough already (cf < 1): pad x.  box 80 x 180 -> cf = 4/3 * 80/180 = 0.5926 -> length = round(80/cf) = 135
+    sl, new, pad = P.crop_box([30.4, 20.5, 110.5, 200.49], 384, 288)
+    assert sl == (30, 20, 110, 200)            # round-half-even: 20.5 -> 20, 110.5 -> 110
+    assert new == (70 - 67, 20, 70 + 67, 200) and pad == (0, 0, 27, 27)
+    # wide (cf > 1): pad y
+    sl, new, pad = P.crop_box([100.5, 50.5, 300.2, 120.7], 384, 288)
+    assert sl == (100, 50, 300, 121)
+    length = int(round(71 * (384 / 288 * 200 / 71)))
+    assert new == (100, 85 - length // 2, 300, 85 + length // 2) and pad == (50 - new[1], new[3] - 121, 0, 0)
+    # exact aspect: untouched
+    assert P.crop_box([10, 10, 58, 74], 64, 48) == ((10, 10, 58, 74), (10, 10, 58, 74), (0, 0, 0, 0))
+
+
+def test_oracle_matches_fixture():
+    g = golden("prepath_240x320_to_96x64")
+    images, boxes = P.prepath(g["frame"], g["dets"], int(g["h"]), int(g["w"]))
+    np.testing.assert_array_equal(boxes, g["boxes"])
+    np.testing.assert_array_equal(images, g["images"])     # restated resampler == Pillow's, bit for bit
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_pkg()
+    return p
+
+
+def _frame(hf, wf, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:hf, 0:wf]
+    f = np.stack([(xx * 255 // wf), (yy * 255 // hf), ((xx + yy) * 255 // (hf + wf))], -1).astype(np.int32)
+    return np.clip(f + rng.integers(-50, 51, f.shape), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_gpu_prepath_matches_fixture_bit_exact(pkg):
+    g = golden("prepath_240x320_to_96x64")
+    net = pkg.NativeHRNet(32, 17, (int(g["h"]), int(g["w"])), "fp32", max_batch=4, device=0)
+    images, boxes, boxes_dev = net.preprocess_frame(g["frame"], g["dets"])
+    np.testing.assert_array_equal(boxes, g["boxes"])
+    np.testing.assert_array_equal(boxes_dev.cpu().numpy(), g["boxes"])
+    np.testing.assert_array_equal(images.cpu().numpy(), g["images"])
+    net.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,hf,wf,seed", [((384, 288), 720, 1280, 1), ((256, 192), 480, 640, 2), ((64, 96), 333, 517, 3)])
+def test_gpu_prepath_random_boxes_vs_oracle(pkg, res, hf, wf, seed):
+    rng = np.random.default_rng(seed)
+    frame = _frame(hf, wf, seed)
+    dets = []
+    for _ in range(12):  # random people: any aspect, some touching the frame edges, some tiny, some huge
+        bw, bh = rng.integers(6, wf), rng.integers(6, hf)
+        x1, y1 = rng.uniform(0, wf - bw), rng.uniform(0, hf - bh)
+        dets.append([x1, y1, x1 + bw + rng.uniform(-0.49, 0.49), y1 + bh + rng.uniform(-0.49, 0.49), 0.9, 0.9, 0])
+    dets += [[0, 0, wf, hf, 1, 1, 0], [0.5, 1.5, 2.5, 3.5, 1, 1, 0]]      # whole frame; ties in the rounding
+    dets = np.asarray(dets, np.float32)
+    dets[:, 2] = np.minimum(dets[:, 2], wf)
+    dets[:, 3] = np.minimum(dets[:, 3], hf)
+    ref_images, ref_boxes = P.prepath(frame, dets, res[0], res[1])
+    net = pkg.NativeHRNet(32, 17, res, "bf16", max_batch=4, device=0)
+    images, boxes, _ = net.preprocess_frame(torch.from_numpy(frame), dets)
+    np.testing.assert_array_equal(boxes, ref_boxes)
+    np.testing.assert_array_equal(images.cpu().numpy(), ref_images)
+    # and again (scratch buffers are reused), with fewer people
+    images2, boxes2, _ = net.preprocess_frame(torch.from_numpy(frame).cuda(), dets[:3])
+    np.testing.assert_array_equal(images2.cpu().numpy(), ref_images[:3])
+    net.close()
+
+
+@pytest.mark.gpu
+def test_gpu_frame_to_joints_and_errors(pkg):
+    from oracle import hrnet_torch_oracle as T
+    c, res = 32, (128, 96)
+    frame = _frame(360, 480, 9)
+    dets = np.asarray([[40.2, 30.7, 200.1, 330.3, .9, .9, 0], [250.5, 100.5, 460.4, 200.6, .8, .8, 0]], np.float32)
+    sd = state_dict_np(c, 4)
+    net = pkg.NativeHRNet(c, 17, res, "fp32", max_batch=4, device=0).load_state_dict(sd)
+    boxes, pts, hm = net.predict_frame(frame, dets, return_heatmaps=True)
+    ref_images, ref_boxes = P.prepath(frame, dets, *res)
+    ref_hm, ref_pts = T.predict_crops(pkg.synth.to_torch_state_dict(sd), torch.from_numpy(ref_images), ref_boxes)
+    np.testing.assert_array_equal(boxes, ref_boxes)
+    np.testing.assert_allclose(hm.cpu().numpy(), ref_hm, rtol=0, atol=2e-4)
+    np.testing.assert_array_equal(pts.cpu().numpy()[..., :2], ref_pts[..., :2])
+    # no people: empty results, no launch
+    b0, p0 = net.predict_frame(frame, np.zeros((0, 7), np.float32))
+    assert b0.shape == (0, 4) and tuple(p0.shape) == (0, 17, 3)
+    # a box outside the frame / degenerate: loud failure (the reference would wrap around or divide by zero)
+    for bad in ([[-5, 10, 50, 100]], [[10, 10, 10, 100]], [[500, 10, 600, 100]]):
+        with pytest.raises((ValueError, RuntimeError)):
+            net.preprocess_frame(frame, np.asarray(bad, np.float32))
+    net.close()
