@@ -102,10 +102,15 @@ int hrn_forward(hrn_handle h, const void *images_dev, int n, const void *boxes_d
  *   images_dev  out: (n,3,H,W) float32, device
  *   boxes_host  out: (n,4) int32 [x1,y1,x2,y2] = the padded boxes the decode scales by (may be NULL)
  *   boxes_dev   out: the same on the device, ready for hrn_forward(..., HRN_BOX_I32, ...) (may be NULL)
+ *   variant     HRN_CROP_PAD (0): single-image path, aspect ratio corrected by zero padding (:243-276);
+ *               HRN_CROP_CLAMP (1): the batch path's enlarge-and-clamp, no padding (SimpleHRNet.py:383-412) -- call once
+ *               per image of the stack
  * Boxes must lie inside the frame after rounding (the detector wrappers clamp them: YOLOv3.py:49-56) and be
  * non-degenerate; otherwise the call fails (the reference would wrap around / divide by zero). */
+enum { HRN_CROP_PAD = 0, HRN_CROP_CLAMP = 1 };
 int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, int frame_w, const float *dets_host,
-                         int det_stride, int n, float *images_dev, int32_t *boxes_host, int32_t *boxes_dev, void *stream);
+                         int det_stride, int n, int variant, float *images_dev, int32_t *boxes_host, int32_t *boxes_dev,
+                         void *stream);
 
 /* Introspection used by tests, bench.py and the roofline accounting. */
 int hrn_conv_count(hrn_handle h);

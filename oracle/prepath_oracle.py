@@ -50,6 +50,24 @@ def crop_box(det, height: int, width: int):
     return (x1, y1, x2, y2), (x1n, y1n, x2n, y2n), (pt, pb, pl, pr)
 
 
+def crop_box_clamped(det, height: int, width: int, frame_h: int, frame_w: int):
+    """``SimpleHRNet.py:386-407`` (the batch path): the aspect ratio is corrected by ENLARGING the box, clamped to the
+    frame; no padding.  Returns the box that is both sliced and reported."""
+    x1, y1, x2, y2 = (py_round(v) for v in det[:4])
+    correction_factor = height / width * (x2 - x1) / (y2 - y1)
+    if correction_factor > 1:
+        center = y1 + (y2 - y1) // 2
+        length = int(round((y2 - y1) * correction_factor))
+        y1 = max(0, center - length // 2)
+        y2 = min(frame_h, center + length // 2)
+    elif correction_factor < 1:
+        center = x1 + (x2 - x1) // 2
+        length = int(round((x2 - x1) * 1 / correction_factor))
+        x1 = max(0, center - length // 2)
+        x2 = min(frame_w, center + length // 2)
+    return x1, y1, x2, y2
+
+
 def _bilinear(x: float) -> float:  # Resample.c: bilinear_filter, support 1.0
     if x < 0.0:
         x = -x
@@ -133,6 +151,18 @@ def prepath(frame_bgr: np.ndarray, dets: np.ndarray, height: int, width: int, re
             crop = np.pad(crop, ((pt, pb), (pl, pr), (0, 0)))
         images[i] = to_tensor_normalize(resize(np.ascontiguousarray(crop), height, width))
         boxes[i] = new
+    return images, boxes
+
+
+def prepath_clamped(frame_bgr: np.ndarray, dets: np.ndarray, height: int, width: int, resize=pil_bilinear_u8):
+    """``SimpleHRNet.py:383-412`` for ONE image of the stack: enlarge-and-clamp boxes, slice as RGB, transform."""
+    p = len(dets)
+    images = np.empty((p, 3, height, width), np.float32)
+    boxes = np.empty((p, 4), np.int32)
+    for i, det in enumerate(dets):
+        x1, y1, x2, y2 = crop_box_clamped(det, height, width, frame_bgr.shape[0], frame_bgr.shape[1])
+        images[i] = to_tensor_normalize(resize(np.ascontiguousarray(frame_bgr[y1:y2, x1:x2, ::-1]), height, width))
+        boxes[i] = (x1, y1, x2, y2)
     return images, boxes
 
 

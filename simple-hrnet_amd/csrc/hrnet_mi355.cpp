@@ -1152,10 +1152,15 @@ int hrn_forward(hrn_handle h, const void *images_dev, int n, const void *boxes_d
 // SimpleHRNet.py:236-278.  The box arithmetic is Python's, restated in double: round() is round-half-even on a
 // float, `//` on non-negative ints is C's `/`, int(round(x)) = nearbyint under the default rounding mode.
 int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, int frame_w, const float *dets_host,
-                         int det_stride, int n, float *images_dev, int32_t *boxes_host, int32_t *boxes_dev, void *stream) {
+                         int det_stride, int n, int variant, float *images_dev, int32_t *boxes_host, int32_t *boxes_dev,
+                         void *stream) {
     if (!h) return 1;
     if (h->plan_only) {
         h->err = "plan-only handle (device_id < 0): there is no CPU compute path";
+        return 7;
+    }
+    if (variant != HRN_CROP_PAD && variant != HRN_CROP_CLAMP) {
+        h->err = "variant must be HRN_CROP_PAD or HRN_CROP_CLAMP";
         return 7;
     }
     if (n < 0 || det_stride < 4 || frame_h <= 0 || frame_w <= 0 || (n > 0 && (!frame_dev || !dets_host || !images_dev))) {
@@ -1179,7 +1184,23 @@ int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, in
         }
         const double cf = (double)H / (double)W * (double)(x2 - x1) / (double)(y2 - y1);
         long x1n = x1, x2n = x2, y1n = y1, y2n = y2, pt = 0, pb = 0, pl = 0, pr = 0;
-        if (cf > 1) {  // increase y side
+        long sx1 = x1, sy1 = y1, sx2 = x2, sy2 = y2;  // what is sliced out of the frame
+        if (variant == HRN_CROP_CLAMP) {  // SimpleHRNet.py:396-407: enlarge, clamp to the frame, slice the enlarged box
+            if (cf > 1) {
+                const long center = y1 + (y2 - y1) / 2;
+                const long length = (long)std::nearbyint((double)(y2 - y1) * cf);
+                y1n = std::max<long>(0, center - length / 2), y2n = std::min<long>(frame_h, center + length / 2);
+            } else if (cf < 1) {
+                const long center = x1 + (x2 - x1) / 2;
+                const long length = (long)std::nearbyint((double)(x2 - x1) * 1 / cf);
+                x1n = std::max<long>(0, center - length / 2), x2n = std::min<long>(frame_w, center + length / 2);
+            }
+            sx1 = x1n, sy1 = y1n, sx2 = x2n, sy2 = y2n;
+            if (sx2 <= sx1 || sy2 <= sy1) {
+                h->err = "detection " + std::to_string(i) + " is degenerate after clamping";
+                return 7;
+            }
+        } else if (cf > 1) {  // increase y side
             const long center = y1 + (y2 - y1) / 2;
             const long length = (long)std::nearbyint((double)(y2 - y1) * cf);
             y1n = center - length / 2, y2n = center + length / 2;
@@ -1191,8 +1212,8 @@ int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, in
             pl = std::labs(x1n - x1), pr = std::labs(x2n - x2);
         }
         CropParams &cp = cps[i];
-        cp.x1 = (int)x1, cp.y1 = (int)y1;
-        cp.w_crop = (int)(std::min<long>(x2, frame_w) - x1), cp.h_crop = (int)(std::min<long>(y2, frame_h) - y1);  // numpy slicing
+        cp.x1 = (int)sx1, cp.y1 = (int)sy1;
+        cp.w_crop = (int)(std::min<long>(sx2, frame_w) - sx1), cp.h_crop = (int)(std::min<long>(sy2, frame_h) - sy1);  // numpy slicing
         cp.pad_top = (int)pt, cp.pad_left = (int)pl;
         cp.h_pad = cp.h_crop + (int)(pt + pb), cp.w_pad = cp.w_crop + (int)(pl + pr);
         cp.tmp_off = (long long)tmp_bytes;

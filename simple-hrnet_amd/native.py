@@ -198,13 +198,17 @@ class NativeHRNet:
         return (hm, pts) if return_heatmaps else pts
 
     # -- introspection --------------------------------------------------------------------------
-    def preprocess_frame(self, frame: torch.Tensor, detections) -> Tuple[torch.Tensor, np.ndarray, torch.Tensor]:
+    def preprocess_frame(self, frame: torch.Tensor, detections, variant: str = "pad") -> Tuple[torch.Tensor, np.ndarray, torch.Tensor]:
         """The crop pre-path of ``SimpleHRNet.predict`` for one frame (``SimpleHRNet.py:236-278``) on the GPU.
 
         ``frame``: (Hf, Wf, 3) uint8 BGR (the cv2 frame; host tensors / arrays are uploaded once);
         ``detections``: (P, >=4) float array-like, columns 0..3 = x1, y1, x2, y2 as the detector returns them.
+        ``variant``: ``"pad"`` = the single-image path (aspect ratio corrected by zero padding), ``"clamp"`` = the batch
+        path's enlarge-and-clamp (``SimpleHRNet.py:383-412``; call once per image of the stack).
         Returns ``(images (P,3,H,W) float32 on the GPU, boxes (P,4) int32 numpy, boxes on the GPU)`` -- bit-identical
-        to the reference's ``ToPILImage -> Resize -> ToTensor -> Normalize`` of the padded RGB crops."""
+        to the reference's ``ToPILImage -> Resize -> ToTensor -> Normalize`` of the RGB crops."""
+        if variant not in ("pad", "clamp"):
+            raise ValueError("variant must be 'pad' or 'clamp'")
         if not isinstance(frame, torch.Tensor):
             frame = torch.from_numpy(np.ascontiguousarray(frame))
         if frame.dtype != torch.uint8 or frame.dim() != 3 or frame.shape[2] != 3:
@@ -222,15 +226,16 @@ class NativeHRNet:
         if p:
             with torch.cuda.device(self.device_index):
                 rc = self._lib.hrn_preprocess_frame(self._h, frame.data_ptr(), int(frame.shape[0]), int(frame.shape[1]),
-                                                    dets.ctypes.data, int(dets.shape[1]), p, images.data_ptr(),
+                                                    dets.ctypes.data, int(dets.shape[1]), p, 0 if variant == "pad" else 1,
+                                                    images.data_ptr(),
                                                     boxes.ctypes.data, boxes_dev.data_ptr(), self._stream())
             self._check(rc, "hrn_preprocess_frame")
         return images, boxes, boxes_dev
 
-    def predict_frame(self, frame, detections, return_heatmaps: bool = False):
+    def predict_frame(self, frame, detections, return_heatmaps: bool = False, variant: str = "pad"):
         """pre-path + model + decode for one frame: what ``SimpleHRNet._predict_single`` does after the detector.
         Returns ``(boxes (P,4) int32 numpy, pts (P,J,3) on the GPU[, heatmaps])``."""
-        images, boxes, boxes_dev = self.preprocess_frame(frame, detections)
+        images, boxes, boxes_dev = self.preprocess_frame(frame, detections, variant)
         out = self.predict_crops(images, boxes_dev, return_heatmaps=return_heatmaps)
         if return_heatmaps:
             return boxes, out[1], out[0]

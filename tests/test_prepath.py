@@ -68,9 +68,18 @@ def test_gpu_prepath_matches_fixture_bit_exact(pkg):
     net.close()
 
 
+def test_box_arithmetic_clamped_variant():
+    # SimpleHRNet.py:396-407: enlarge the short side around its centre, clamp to the frame
+    assert P.crop_box_clamped([100.5, 50.5, 300.2, 120.7], 384, 288, 240, 320) == (100, 0, 300, 218)   # y grows, top clamps
+    assert P.crop_box_clamped([30.4, 20.5, 110.5, 200.49], 384, 288, 240, 320) == (3, 20, 137, 200)     # x grows
+    assert P.crop_box_clamped([300, 10, 318, 200], 384, 288, 240, 320)[2] == 320                         # right edge clamps
+    assert P.crop_box_clamped([10, 10, 58, 74], 64, 48, 240, 320) == (10, 10, 58, 74)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["pad", "clamp"])
 @pytest.mark.parametrize("res,hf,wf,seed", [((384, 288), 720, 1280, 1), ((256, 192), 480, 640, 2), ((64, 96), 333, 517, 3)])
-def test_gpu_prepath_random_boxes_vs_oracle(pkg, res, hf, wf, seed):
+def test_gpu_prepath_random_boxes_vs_oracle(pkg, res, hf, wf, seed, variant):
     rng = np.random.default_rng(seed)
     frame = _frame(hf, wf, seed)
     dets = []
@@ -82,13 +91,14 @@ def test_gpu_prepath_random_boxes_vs_oracle(pkg, res, hf, wf, seed):
     dets = np.asarray(dets, np.float32)
     dets[:, 2] = np.minimum(dets[:, 2], wf)
     dets[:, 3] = np.minimum(dets[:, 3], hf)
-    ref_images, ref_boxes = P.prepath(frame, dets, res[0], res[1])
+    ref = P.prepath if variant == "pad" else P.prepath_clamped
+    ref_images, ref_boxes = ref(frame, dets, res[0], res[1])
     net = pkg.NativeHRNet(32, 17, res, "bf16", max_batch=4, device=0)
-    images, boxes, _ = net.preprocess_frame(torch.from_numpy(frame), dets)
+    images, boxes, _ = net.preprocess_frame(torch.from_numpy(frame), dets, variant)
     np.testing.assert_array_equal(boxes, ref_boxes)
     np.testing.assert_array_equal(images.cpu().numpy(), ref_images)
     # and again (scratch buffers are reused), with fewer people
-    images2, boxes2, _ = net.preprocess_frame(torch.from_numpy(frame).cuda(), dets[:3])
+    images2, boxes2, _ = net.preprocess_frame(torch.from_numpy(frame).cuda(), dets[:3], variant)
     np.testing.assert_array_equal(images2.cpu().numpy(), ref_images[:3])
     net.close()
 
