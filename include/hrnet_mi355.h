@@ -112,6 +112,18 @@ int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, in
                          int det_stride, int n, int variant, float *images_dev, int32_t *boxes_host, int32_t *boxes_dev,
                          void *stream);
 
+/* Flip test-time augmentation + evaluation decode (testing/Test.py:132-140,
+ * training/COCO.py:206-230, misc/utils.py:9-29 flip_tensor / flip_back, :125-151 get_max_preds, :154-175 the
+ * post-processing of get_final_preds):
+ *   heatmaps = (model(images) + flip_back(model(flip(images)), flip_pairs)) * 0.5      -> heatmaps_dev (n,J,h,w)
+ *   preds    = arg-max of each map as (x, y) in heat-map pixels, zero where the maximum is <= 0, moved a quarter
+ *              pixel towards the higher neighbour when post_processing != 0            -> preds_dev (n,J,2)
+ *   maxvals  = the maxima                                                              -> maxvals_dev (n,J)
+ * flip_pairs_host: npairs x 2 joint indices that swap under mirroring (COCO: datasets/COCO.py:113).  The inverse
+ * affine of get_final_preds (transform_preds, cv2) stays with the caller. */
+int hrn_forward_flip_tta(hrn_handle h, const void *images_dev, int n, const int32_t *flip_pairs_host, int npairs,
+                         int post_processing, float *heatmaps_dev, float *preds_dev, float *maxvals_dev, void *stream);
+
 /* Introspection used by tests, bench.py and the roofline accounting. */
 int hrn_conv_count(hrn_handle h);
 int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out);

@@ -24,6 +24,7 @@ itself, run in the build container" (tests/golden/make_golden.py).
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, List, Sequence
 
 import numpy as np
@@ -164,3 +165,39 @@ def cast_state_dict(sd: Dict, dtype=torch.float64) -> Dict:
         t = _t(sd, k)
         out[k] = t.to(dtype) if t.is_floating_point() else t
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Flip test-time augmentation + evaluation decode.  Restates testing/Test.py:132-140,
+# misc/utils.py:9-29 (flip_tensor / flip_back), :125-151 (get_max_preds) and the post-processing loop of
+# get_final_preds (:162-175).  The inverse affine (transform_preds, cv2) is out of scope.  Pinned to the reference's
+# own functions through tests/golden/w32_128x96_fliptta_n3.npz.
+def flip_tta_heatmaps(sd, images: torch.Tensor, flip_pairs) -> torch.Tensor:
+    """``(model(x) + flip_back(model(flip(x)), pairs)) * 0.5`` -> (n,J,h,w) fp32."""
+    out = hrnet_forward(sd, images)
+    out_f = hrnet_forward(sd, torch.flip(images, dims=[-1]))
+    out_f = torch.flip(out_f, dims=[-1]).clone()
+    for a, b in flip_pairs:
+        tmp = out_f[:, a].clone()
+        out_f[:, a] = out_f[:, b]
+        out_f[:, b] = tmp
+    return (out + out_f) * 0.5
+
+
+def max_preds_refined(heatmaps: np.ndarray, post_processing: bool = True):
+    """``get_max_preds`` + the quarter-pixel refinement: heat-maps (n,J,h,w) -> preds (n,J,2) = (x, y), maxvals (n,J,1)."""
+    n, nj, h, w = heatmaps.shape
+    flat = heatmaps.reshape(n, nj, -1)
+    idx = flat.argmax(-1)                       # first maximum, like torch.max
+    maxvals = np.take_along_axis(flat, idx[..., None], -1).astype(np.float32)
+    preds = np.stack([(idx % w).astype(np.float32), (idx // w).astype(np.float32)], -1)
+    preds *= (maxvals > 0.0).astype(np.float32)
+    if post_processing:
+        for i in range(n):
+            for j in range(nj):
+                px, py = int(math.floor(preds[i, j, 0] + 0.5)), int(math.floor(preds[i, j, 1] + 0.5))
+                if 1 < px < w - 1 and 1 < py < h - 1:
+                    hm = heatmaps[i, j]
+                    preds[i, j, 0] += np.sign(hm[py, px + 1] - hm[py, px - 1]) * np.float32(0.25)
+                    preds[i, j, 1] += np.sign(hm[py + 1, px] - hm[py - 1, px]) * np.float32(0.25)
+    return preds, maxvals

@@ -90,6 +90,7 @@ SYMBOLS = {
     "hrn_weight_blob_read": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int64]),
     "hrn_forward": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P]),
     "hrn_preprocess_frame": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
+    "hrn_forward_flip_tta": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
     "hrn_conv_count": (ctypes.c_int, [_P]),
     "hrn_get_conv_info": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ConvInfo)]),
     "hrn_flops_per_crop": (ctypes.c_double, [_P]),

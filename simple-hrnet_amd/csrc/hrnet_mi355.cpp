@@ -158,6 +158,7 @@ struct hrn_ctx {
     size_t pre_tmp_bytes = 0;
     CropParams *pre_params = nullptr;
     int pre_params_cap = 0;
+    float *tta_hm = nullptr;  // flip-TTA: heat-maps of the mirrored micro-batch (allocated on first use)
     int64_t workspace_bytes = 0;
 
     // ---------------------------------------------------------------- planning
@@ -705,6 +706,7 @@ struct hrn_ctx {
             for (auto &b : buffers)
                 if (b.dev) (void)hipFree(b.dev);
             if (blob) (void)hipFree(blob);
+            if (tta_hm) (void)hipFree(tta_hm);
             if (pre_tmp) (void)hipFree(pre_tmp);
             if (pre_params) (void)hipFree(pre_params);
             if (part_val) (void)hipFree(part_val);
@@ -903,7 +905,7 @@ struct hrn_ctx {
     };
 
     bool run_pass(const float *images, int nb, const void *boxes, int box_dtype, float *pts, float *heatmaps,
-                  hipStream_t s, Timing *tm) {
+                  hipStream_t s, Timing *tm, int flip = 0) {
         if (tm && !hip_ok(hipEventRecord(tm->ev[0], s), "hipEventRecord")) return false;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op &op = ops[oi];
@@ -920,6 +922,7 @@ struct hrn_ctx {
                     a.wp = (dtype == HRN_BF16 && !disable_stem_mfma) ? (const void *)(blob + stem_wp_off) : nullptr;
                     a.n = nb, a.H = H, a.W = W;
                     a.out_h = t.h, a.out_w = t.w, a.out_wp = t.wp, a.out_hpwp = t.hpwp;
+                    a.flip = flip;
                     e = launch_stem(dtype, a, s);
                     break;
                 }
@@ -1145,6 +1148,48 @@ int hrn_forward(hrn_handle h, const void *images_dev, int n, const void *boxes_d
         float *p = pts_dev ? pts_dev + (size_t)off * h->joints * 3 : nullptr;
         float *hp = heatmaps_dev ? heatmaps_dev + (size_t)off * h->joints * hm : nullptr;
         if (!h->run_pass(img, nb, bx, box_dtype, p, hp, (hipStream_t)stream, nullptr)) return 8;
+    }
+    return 0;
+}
+
+// Flip test-time augmentation + the evaluation decode (testing/Test.py:132-140, training/COCO.py:206-230,
+// misc/utils.py:9-29, 125-175): two passes per micro-batch (the second reads the crops mirrored in the stem), then one
+// kernel averages, finds the maxima and applies the quarter-pixel refinement.
+int hrn_forward_flip_tta(hrn_handle h, const void *images_dev, int n, const int32_t *flip_pairs_host, int npairs,
+                         int post_processing, float *heatmaps_dev, float *preds_dev, float *maxvals_dev, void *stream) {
+    if (!h) return 1;
+    if (!h->check_forward_args(images_dev, n, nullptr, nullptr, heatmaps_dev ? heatmaps_dev : (float *)nullptr)) return 7;
+    if (!heatmaps_dev || !preds_dev || !maxvals_dev || npairs < 0 || (npairs > 0 && !flip_pairs_host)) {
+        h->err = "heatmaps, preds and maxvals are required outputs; flip_pairs must be npairs x 2";
+        return 7;
+    }
+    TtaArgs a;
+    for (int j = 0; j < 32; ++j) a.pair[j] = j;
+    for (int k = 0; k < npairs; ++k) {
+        const int p0 = flip_pairs_host[2 * k], p1 = flip_pairs_host[2 * k + 1];
+        if (p0 < 0 || p1 < 0 || p0 >= h->joints || p1 >= h->joints) {
+            h->err = "flip pair out of range";
+            return 7;
+        }
+        a.pair[p0] = p1, a.pair[p1] = p0;
+    }
+    if (n == 0) return 0;
+    if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return 6;
+    const int hh = h->H / 4, ww = h->W / 4, hm = hh * ww;
+    if (!h->tta_hm &&
+        !h->hip_ok(hipMalloc((void **)&h->tta_hm, (size_t)h->max_batch * h->joints * hm * sizeof(float)), "hipMalloc(flip-TTA)"))
+        return 6;
+    hipStream_t s = (hipStream_t)stream;
+    for (int off = 0; off < n; off += h->max_batch) {
+        const int nb = n - off < h->max_batch ? n - off : h->max_batch;
+        const float *img = (const float *)images_dev + (size_t)off * 3 * h->H * h->W;
+        float *out = heatmaps_dev + (size_t)off * h->joints * hm;
+        if (!h->run_pass(img, nb, nullptr, 0, nullptr, out, s, nullptr, 0)) return 8;
+        if (!h->run_pass(img, nb, nullptr, 0, nullptr, h->tta_hm, s, nullptr, 1)) return 8;
+        a.hm = out, a.hm_flipped = h->tta_hm;
+        a.preds = preds_dev + (size_t)off * h->joints * 2, a.maxvals = maxvals_dev + (size_t)off * h->joints;
+        a.n = nb, a.joints = h->joints, a.h = hh, a.w = ww, a.post_processing = post_processing;
+        if (!h->hip_ok(launch_tta_decode(a, s), "flip-TTA decode launch")) return 8;
     }
     return 0;
 }

@@ -75,6 +75,7 @@ struct StemArgs {          // conv1 3->64 3x3 s2 + BN + ReLU, NCHW fp32 in, flat
     const void *wp;        // bf16 mode: MFMA image of the weights, [4 frags][64 lanes][8 bf16], K = 27 padded to 32
     int n, H, W;           // input size
     int out_h, out_w, out_wp, out_hpwp;
+    int flip;              // read the crops mirrored left-right (flip-TTA: misc/utils.py flip_tensor(image, dim=-1))
 };
 
 // Crop pre-path (prepath.hip): one person's slice of the frame, its zero padding and where its horizontal pass lives
@@ -120,6 +121,16 @@ struct DecodeArgs {        // SimpleHRNet.py:297-308
     float *pts;            // (n,joints,3)
     int n, joints, h, w, slabs;
 };
+
+struct TtaArgs {           // flip-TTA combine + get_max_preds + quarter-pixel refinement (misc/utils.py:19-29, 125-175)
+    float *hm;             // (n,joints,h,w): plain pass in, average out
+    const float *hm_flipped;  // the mirrored crops' heat-maps
+    float *preds;          // (n,joints,2): x, y in heat-map pixels
+    float *maxvals;        // (n,joints)
+    int pair[32];          // joint j of the mirrored output is joint pair[j] (flip_back)
+    int n, joints, h, w, post_processing;
+};
+hipError_t launch_tta_decode(const TtaArgs &a, hipStream_t s);
 
 hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s);
 // grouped launch of the generic kernel: device-resident ConvArgs[], block map entries (prob | cout tile << 8, M tile)

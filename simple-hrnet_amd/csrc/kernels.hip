@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs p) {
             for (int kw = 0; kw < 3; ++kw) {
                 const int ix = 2 * wo + kw - 1;
                 float v = 0.f;
-                if (ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = img[((size_t)ci * p.H + iy) * p.W + ix];
+                if (ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                    v = img[((size_t)ci * p.H + iy) * p.W + (p.flip ? p.W - 1 - ix : ix)];  // flip: the mirrored crop (flip-TTA)
                 x[ci * 9 + kh * 3 + kw] = v;
             }
         }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs p) {
             const int iy = 2 * ho + dkh[e], ix = 2 * wo + dkw[e];
             float v = 0.f;
             if (okp[i] && g * 8 + e < 27 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                v = img[((size_t)dci[e] * p.H + iy) * p.W + ix];
+                v = img[((size_t)dci[e] * p.H + iy) * p.W + (p.flip ? p.W - 1 - ix : ix)];
             xf[e] = (short)f32_to_bf16(v);
         }
 #pragma unroll
@@ -716,6 +717,59 @@ __global__ void decode_kernel(const DecodeArgs p) {
     o[0] = (float)((double)py * 1. / (double)p.h * dy + y1);
     o[1] = (float)((double)px * 1. / (double)p.w * dx + x1);
     o[2] = v;
+}
+
+// Flip-TTA combine + decode (testing/Test.py:134-140, misc/utils.py:19-29, 125-175): per (crop, joint)
+//   avg = (hm[j] + mirror(hm_flipped[pair(j)])) * 0.5     written back over hm
+//   (max, first arg-max) of avg -> x = idx % w, y = idx / w, zeroed when max <= 0   (get_max_preds)
+//   post_processing: +-0.25 px towards the higher neighbour when 1 < x < w-1 and 1 < y < h-1   (get_final_preds)
+__global__ __launch_bounds__(256) void tta_decode_kernel(const TtaArgs p) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int j = blockIdx.x, n = blockIdx.y, hw = p.h * p.w;
+    float *hm = p.hm + ((size_t)n * p.joints + j) * hw;
+    const float *hf = p.hm_flipped + ((size_t)n * p.joints + p.pair[j]) * hw;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int px = threadIdx.x; px < hw; px += 256) {
+        const int y = px / p.w, x = px - y * p.w;
+        const float v = (hm[px] + hf[y * p.w + (p.w - 1 - x)]) * 0.5f;
+        hm[px] = v;
+        if (v > bv) bv = v, bi = px;  // px grows: strict > keeps the first maximum
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        if (better(ov, oi, bv, bi)) bv = ov, bi = oi;
+    }
+    if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = bv, si[threadIdx.x >> 6] = bi;
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better(sv[w], si[w], bv, bi)) bv = sv[w], bi = si[w];
+        float x = (float)(bi % p.w), y = (float)(bi / p.w);
+        if (!(bv > 0.f)) x = 0.f, y = 0.f;
+        if (p.post_processing) {
+            const int ix = (int)x, iy = (int)y;  // integer valued
+            if (1 < ix && ix < p.w - 1 && 1 < iy && iy < p.h - 1) {
+                const float dx = hm[iy * p.w + ix + 1] - hm[iy * p.w + ix - 1];
+                const float dy = hm[(iy + 1) * p.w + ix] - hm[(iy - 1) * p.w + ix];
+                x += (dx > 0.f ? 0.25f : (dx < 0.f ? -0.25f : 0.f));
+                y += (dy > 0.f ? 0.25f : (dy < 0.f ? -0.25f : 0.f));
+            }
+        }
+        p.preds[((size_t)n * p.joints + j) * 2 + 0] = x;
+        p.preds[((size_t)n * p.joints + j) * 2 + 1] = y;
+        p.maxvals[(size_t)n * p.joints + j] = bv;
+    }
+}
+
+hipError_t launch_tta_decode(const TtaArgs &a, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tta_decode_kernel, dim3(a.joints, a.n), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t s) {

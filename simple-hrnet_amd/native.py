@@ -198,6 +198,25 @@ class NativeHRNet:
         return (hm, pts) if return_heatmaps else pts
 
     # -- introspection --------------------------------------------------------------------------
+    def predict_flip_tta(self, images: torch.Tensor, flip_pairs, post_processing: bool = True):
+        """Flip test-time augmentation + evaluation decode (``testing/Test.py:132-140``, ``misc/utils.py:9-29, 125-175``):
+        returns ``(heatmaps (n,J,h,w) averaged over the crop and its mirror image, preds (n,J,2) = (x, y) in heat-map
+        pixels with the quarter-pixel refinement, maxvals (n,J,1))`` -- what ``get_final_preds`` works on before its
+        inverse affine."""
+        x = self._images_ptr(images)
+        n = x.shape[0]
+        fp = np.ascontiguousarray(np.asarray(flip_pairs, dtype=np.int32).reshape(-1, 2))
+        h, w = self.resolution
+        hm = torch.empty((n, self.nof_joints, h // 4, w // 4), dtype=torch.float32, device=x.device)
+        preds = torch.empty((n, self.nof_joints, 2), dtype=torch.float32, device=x.device)
+        maxvals = torch.empty((n, self.nof_joints, 1), dtype=torch.float32, device=x.device)
+        if n:
+            with torch.cuda.device(self.device_index):
+                self._check(self._lib.hrn_forward_flip_tta(self._h, x.data_ptr(), n, fp.ctypes.data, len(fp),
+                                                           1 if post_processing else 0, hm.data_ptr(), preds.data_ptr(),
+                                                           maxvals.data_ptr(), self._stream()), "hrn_forward_flip_tta")
+        return hm, preds, maxvals
+
     def preprocess_frame(self, frame: torch.Tensor, detections, variant: str = "pad") -> Tuple[torch.Tensor, np.ndarray, torch.Tensor]:
         """The crop pre-path of ``SimpleHRNet.predict`` for one frame (``SimpleHRNet.py:236-278``) on the GPU.
 

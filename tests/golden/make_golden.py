@@ -235,14 +235,43 @@ def predict_cases(yolo):
          heatmaps=np.concatenate(hm, 0), pts=np.concatenate(pts, 0))
 
 
+COCO_FLIP_PAIRS = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]  # datasets/COCO.py:113
+
+
+def flip_tta_case(name, c, n, h, w, seed=0):
+    """Flip test-time augmentation + evaluation decode, by the reference's own functions (testing/Test.py:132-140):
+    ``flip_tensor`` / ``flip_back`` / ``get_final_preds`` of misc/utils.py, imported unmodified.  ``transform_preds``
+    (the inverse affine, cv2.getAffineTransform) is replaced by the identity: our scope ends at heat-map coordinates."""
+    if "munkres" not in sys.modules:
+        sys.modules["munkres"] = types.ModuleType("munkres")
+    import misc.utils as U
+
+    m = ref_model(c, seed)
+    x = torch.from_numpy(synth.synth_crops(n, h, w, seed=13))
+    with torch.no_grad():
+        out = m(x)
+        out_f = U.flip_back(m(U.flip_tensor(x, dim=-1)), COCO_FLIP_PAIRS)
+        avg = (out + out_f) * 0.5
+    U.transform_preds = lambda coords, center, scale, pixel_std, output_size: coords
+    none = [None] * n
+    preds, maxvals = U.get_final_preds(True, avg.clone(), none, none, 200)
+    preds_raw, _ = U.get_final_preds(False, avg.clone(), none, none, 200)
+    save(name, c=c, n=n, h=h, w=w, weight_seed=seed, crops=x.numpy(), heatmaps=avg.numpy(), preds=preds.numpy(),
+         preds_nopost=preds_raw.numpy(), maxvals=maxvals.numpy(), flip_pairs=np.asarray(COCO_FLIP_PAIRS, np.int32))
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     yolo = install_stubs()
+    if len(sys.argv) > 1 and sys.argv[1] == "fliptta":   # only the flip-TTA fixture
+        flip_tta_case("w32_128x96_fliptta_n3", 32, 3, 128, 96, seed=2)
+        return
     heatmap_case("w32_64x64_n2", 32, 2, 64, 64)
     heatmap_case("w48_64x64_n2", 48, 2, 64, 64)
     heatmap_case("w32_256x192_n2", 32, 2, 256, 192, seed=1)
     heatmap_case("w48_384x288_n1", 48, 1, 384, 288)
     predict_cases(yolo)
+    flip_tta_case("w32_128x96_fliptta_n3", 32, 3, 128, 96, seed=2)
 
 
 if __name__ == "__main__":

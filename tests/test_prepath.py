@@ -125,3 +125,54 @@ def test_gpu_frame_to_joints_and_errors(pkg):
         with pytest.raises((ValueError, RuntimeError)):
             net.preprocess_frame(frame, np.asarray(bad, np.float32))
     net.close()
+
+
+# ------------------------------------------------------------- pinned to the unmodified reference predict()
+# tests/golden/make_golden.py ran SimpleHRNet.predict() itself (its box / pad / slice code, :236-278 and :383-412, with
+# PIL-backed stand-ins for the absent torchvision transforms) and stored the crops it handed to the model.  The frames
+# came from default_rng(0) in a fixed order; replaying the draws gives the same pixels.
+def _reference_frames():
+    rng = np.random.default_rng(0)
+    frame1 = rng.integers(0, 256, (720, 1280, 3), dtype=np.uint8)
+    rng.integers(0, 256, (128, 96, 3), dtype=np.uint8)
+    rng.integers(0, 256, (5, 128, 96, 3), dtype=np.uint8)
+    frames3 = rng.integers(0, 256, (3, 480, 640, 3), dtype=np.uint8)
+    return frame1, frames3
+
+
+DETS_SINGLE = np.asarray([[100.2, 50.7, 400.4, 650.1], [600.0, 200.0, 1100.0, 500.0], [5.0, 300.0, 250.0, 700.0]], np.float32)
+DETS_BATCH = {0: np.asarray([[50., 40., 200., 400.], [300., 100., 620., 300.]], np.float32),
+              2: np.asarray([[10., 10., 630., 470.]], np.float32)}
+
+
+def test_oracle_equals_reference_predict_crops():
+    frame1, frames3 = _reference_frames()
+    g = golden("cfg1_w32_256x192_predict_multi")
+    images, boxes = P.prepath(frame1, DETS_SINGLE, 256, 192)
+    np.testing.assert_array_equal(boxes, g["boxes"])
+    np.testing.assert_array_equal(images, g["crops"])
+    g = golden("w32_128x96_predict_batch_multi")
+    parts = [P.prepath_clamped(frames3[d], DETS_BATCH[d], 128, 96) for d in (0, 2)]
+    np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), g["boxes"])
+    np.testing.assert_array_equal(np.concatenate([p[0] for p in parts]), g["crops"])
+
+
+@pytest.mark.gpu
+def test_gpu_equals_reference_predict_crops(pkg):
+    frame1, frames3 = _reference_frames()
+    g = golden("cfg1_w32_256x192_predict_multi")
+    net = pkg.NativeHRNet(32, 17, (256, 192), "fp32", max_batch=4, device=0).load_state_dict(state_dict_np(32, 0))
+    images, boxes, boxes_dev = net.preprocess_frame(frame1, DETS_SINGLE)
+    np.testing.assert_array_equal(boxes, g["boxes"])
+    np.testing.assert_array_equal(images.cpu().numpy(), g["crops"])
+    # the whole of predict() after the detector: frame -> joints, against the reference's own output
+    bx, pts, hm = net.predict_frame(frame1, DETS_SINGLE, return_heatmaps=True)
+    np.testing.assert_allclose(hm.cpu().numpy(), g["heatmaps"], rtol=0, atol=2e-4)
+    np.testing.assert_array_equal(pts.cpu().numpy()[..., :2], g["pts"].reshape(3, 17, 3)[..., :2])
+    net.close()
+    g = golden("w32_128x96_predict_batch_multi")
+    net = pkg.NativeHRNet(32, 17, (128, 96), "fp32", max_batch=4, device=0)
+    outs = [net.preprocess_frame(frames3[d], DETS_BATCH[d], "clamp") for d in (0, 2)]
+    np.testing.assert_array_equal(np.concatenate([o[1] for o in outs]), g["boxes"])
+    np.testing.assert_array_equal(np.concatenate([o[0].cpu().numpy() for o in outs]), g["crops"])
+    net.close()
