@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="crops per GPU per step")
-    ap.add_argument("--c", type=int, default=48)
+    ap.add_argument("--c", type=int, default=48, help="HRNet width, or the ResNet size with --model-name PoseResNet")
+    ap.add_argument("--model-name", default="HRNet", choices=["HRNet", "PoseResNet"],
+                    help="side measurements only: the headline metric is HRNet-W48 (BASELINE.json)")
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=288)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -175,9 +177,9 @@ def main():
     pkg = importlib.import_module("simple-hrnet_amd")
     shard = importlib.import_module("simple-hrnet_amd.dist")
 
-    net = pkg.NativeHRNet(a.c, 17, (a.height, a.width), a.dtype, max_batch=a.max_batch, device=local)
+    net = pkg.NativeHRNet(a.c, 17, (a.height, a.width), a.dtype, max_batch=a.max_batch, device=local, model_name=a.model_name)
     eng = shard.ShardedHRNet(net, dist)
-    eng.load_and_broadcast(pkg.synth_state_dict(a.c, 17, 0) if rank == 0 else None, src=0)
+    eng.load_and_broadcast(pkg.synth_state_dict(a.c, 17, 0, model=a.model_name) if rank == 0 else None, src=0)
 
     # synthetic crops, device resident (post-normalisation domain ~N(0,1)), different per rank
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -214,19 +216,21 @@ def main():
         flops = net.flops_per_crop()
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
         out = {
-            "metric": "person-crops/sec HRNet-W%d %dx%d (model forward + heat-map decode)" % (a.c, a.height, a.width),
+            "metric": "person-crops/sec %s %dx%d (model forward + heat-map decode)"
+                      % ("HRNet-W%d" % a.c if a.model_name == "HRNet" else "PoseResNet-%d" % a.c, a.height, a.width),
             "value": round(value, 2), "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "HRNet-W%d %dx%d, batch=%d random crops per GPU, %s MFMA (BASELINE configs[2])"
-                                   % (a.c, a.height, a.width, a.batch, a.dtype),
+            "config": {"workload": "%s %dx%d, batch=%d random crops per GPU, %s%s"
+                                   % ("HRNet-W%d" % a.c if a.model_name == "HRNet" else "PoseResNet-%d" % a.c, a.height, a.width,
+                                      a.batch, a.dtype, " MFMA (BASELINE configs[2])" if (a.model_name, a.c, a.dtype) == ("HRNet", 48, "bf16") else ""),
                        "global_batch": a.batch * world, "micro_batch": a.max_batch,
                        "parallelism": "dp%d (crop sharding, RCCL all-gather of keypoints)" % world,
                        "weights": "random-init seeded (synth_state_dict seed 0), BN stats randomised"},
             "whole_net_tflops": round(value / world * flops / 1e12, 2),
             "gflop_per_crop": round(flops / 1e9, 3),
         }
-        if not a.no_roofline:
+        if not a.no_roofline and a.model_name == "HRNet":
             # per-kernel HIP-event times of one internal pass, same stream as the launches
             nb = min(a.max_batch, a.batch)
             for _ in range(2):
@@ -269,7 +273,7 @@ def main():
             }
         if world == 1 and not a.no_prepath:
             out["prepath"] = prepath_measure(pkg, net, dev)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.model_name == "HRNet":
             out["cpu_baseline"] = cpu_baseline(a.c, a.height, a.width, a.cpu_seconds)
     if dist:
         dist.barrier()

@@ -67,6 +67,13 @@ typedef struct {
  * hrn_forward fails on such a handle -- there is NO CPU compute path). */
 int hrn_create(hrn_handle *out, int c, int nof_joints, int height, int width, int dtype, int max_batch,
                int device_id);
+
+/* The other model SimpleHRNet offers (model_name='PoseResNet', SimpleHRNet.py:111-112; models_/poseresnet.py:16-122):
+ * c is then the ResNet size (50 / 101 / 152).  hrn_create(...) == hrn_create_model(HRN_MODEL_HRNET, ...).
+ * Everything else of the interface is model independent. */
+enum { HRN_MODEL_HRNET = 0, HRN_MODEL_POSERESNET = 1 };
+int hrn_create_model(hrn_handle *out, int model, int c, int nof_joints, int height, int width, int dtype, int max_batch,
+                     int device_id);
 void hrn_destroy(hrn_handle h);
 const char *hrn_last_error(hrn_handle h); /* h may be NULL: error of the last failed hrn_create */
 

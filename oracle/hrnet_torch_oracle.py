@@ -201,3 +201,35 @@ def max_preds_refined(heatmaps: np.ndarray, post_processing: bool = True):
                     preds[i, j, 0] += np.sign(hm[py, px + 1] - hm[py, px - 1]) * np.float32(0.25)
                     preds[i, j, 1] += np.sign(hm[py + 1, px] - hm[py - 1, px]) * np.float32(0.25)
     return preds, maxvals
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# PoseResNet: models_/poseresnet.py:108-122 restated with torch.nn.functional over the
+# state_dict; Bottleneck = models_/modules.py:19-40.  Pinned by tests/golden/poseresnet50_128x96_n2.npz (the unmodified
+# reference class run in the build container).
+RESNET_LAYERS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+
+def _bn_eval(sd, prefix, x):
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                        sd[prefix + ".bias"], False, 0.0, 1e-5)
+
+
+def poseresnet_forward(sd, x: torch.Tensor, resnet_size: int = 50) -> torch.Tensor:
+    x = F.relu(_bn_eval(sd, "bn1", F.conv2d(x, sd["conv1.weight"], None, 2, 3)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, blocks in enumerate(RESNET_LAYERS[resnet_size]):
+        for b in range(blocks):
+            p = "layer%d.%d" % (li + 1, b)
+            stride = 2 if (b == 0 and li > 0) else 1
+            out = F.relu(_bn_eval(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"])))
+            out = F.relu(_bn_eval(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], None, stride, 1)))
+            out = _bn_eval(sd, p + ".bn3", F.conv2d(out, sd[p + ".conv3.weight"]))
+            res = x
+            if b == 0:
+                res = _bn_eval(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride))
+            x = F.relu(out + res)
+    for i in range(3):
+        x = F.conv_transpose2d(x, sd["deconv_layers.%d.weight" % (3 * i)], None, 2, 1, 0)
+        x = F.relu(_bn_eval(sd, "deconv_layers.%d" % (3 * i + 1), x))
+    return F.conv2d(x, sd["final_layer.weight"], sd["final_layer.bias"])

@@ -81,6 +81,8 @@ _P = ctypes.c_void_p
 SYMBOLS = {
     "hrn_create": (ctypes.c_int, [ctypes.POINTER(_P), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "hrn_create_model": (ctypes.c_int, [ctypes.POINTER(_P), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "hrn_destroy": (None, [_P]),
     "hrn_last_error": (ctypes.c_char_p, [_P]),
     "hrn_load_weights": (ctypes.c_int, [_P, ctypes.POINTER(TensorDesc), ctypes.c_int]),

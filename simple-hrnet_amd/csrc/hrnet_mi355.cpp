@@ -37,7 +37,7 @@ struct Buffer {
     bool in_use = false;
 };
 
-enum OpKind { OP_STEM, OP_CONV, OP_CONV3_GROUP, OP_CONV_GROUP, OP_CHAIN, OP_FUSE, OP_HEAD, OP_DECODE };
+enum OpKind { OP_STEM, OP_STEM7, OP_MAXPOOL, OP_CONV, OP_CONV3_GROUP, OP_CONV_GROUP, OP_CHAIN, OP_FUSE, OP_HEAD, OP_DECODE };
 
 struct ConvOp {
     std::string conv, bn;  // state_dict prefixes ("" bn => plain bias conv)
@@ -45,6 +45,7 @@ struct ConvOp {
     int cin, cout, k, stride, relu;
     int kpad, kchunks, nr;
     int algo = 0;          // 0 = generic kernel (kernels.hip), 1 = pipelined LDS-staged 3x3 stride 1 (conv3x3_lds.hip)
+    int up = 0;            // 1 + 2a + b: phase (a, b) of a ConvTranspose2d(4, s2, p1) as a 3x3 conv on the input grid
     int ks = 0, slices = 0, ntiles = 0, nch = 0;
     int64_t w_off = 0, w_bytes = 0, b_off = 0;
     double flops = 0;
@@ -109,6 +110,9 @@ inline uint16_t f32_to_bf16_host(float f) {
 
 struct hrn_ctx {
     int c, joints, H, W, dtype, max_batch, device;
+    int model = 0;  // 0 = HRNet (c = width), 1 = PoseResNet (c = ResNet size), SimpleHRNet.py:109-112
+    int head_c = 0; // channels of the tensor final_layer reads
+    int pool_in_t = -1, pool_out_t = -1;
     bool plan_only;
     int esize;
     std::string err;
@@ -200,23 +204,24 @@ struct hrn_ctx {
     }
 
     int add_conv(const std::string &conv, const std::string &bn, int in_t, int cout, int k, int stride, int relu,
-                 int res_t = -1, bool emit = true, int nr_override = 0) {
+                 int res_t = -1, bool emit = true, int nr_override = 0, int up = 0, int up_out_t = -1) {
         const Tensor ti = tensors[in_t];  // by value: new_tensor() below may reallocate `tensors`
         ConvOp op;
         op.conv = conv, op.bn = bn, op.in_t = in_t, op.res_t = res_t;
         op.cin = ti.c, op.cout = cout, op.k = k, op.stride = stride, op.relu = relu;
         const int oh = ti.h / stride, ow = ti.w / stride;
-        op.out_t = new_tensor(cout, oh, ow);
+        op.up = up;
+        op.out_t = up ? up_out_t : new_tensor(cout, oh, ow);
         const int kc = dtype == HRN_BF16 ? 32 : 16;
         const int K = k * k * op.cin;
         op.kchunks = (K + kc - 1) / kc;
         op.kpad = op.kchunks * kc;
         op.nr = nr_override ? nr_override : default_nr(cout, stride);
-        op.flops = 2.0 * cout * (double)K * oh * ow;
+        op.flops = 2.0 * cout * (double)(up ? 4 * op.cin : K) * oh * ow;  // a transposed-conv phase has 4 live taps of the 9
         // pipelined LDS kernel (conv3x3_lds.hip): KS = 48 / 48-cout tiles for the HRNet-W48 branch widths, KS = 32 with
         // 64-, 48- or 32-cout tiles for everything else whose channel counts are multiples of 32
         int lds_ks = 0, lds_nrb = 0;
-        if (dtype == HRN_BF16 && k == 3 && stride == 1 && !disable_lds) {
+        if (dtype == HRN_BF16 && k == 3 && stride == 1 && !disable_lds && !up) {
             if (op.cin % 48 == 0 && cout % 48 == 0)
                 lds_ks = 48, lds_nrb = 3;
             else if (op.cin % 32 == 0 && !disable_lds32)
@@ -383,7 +388,66 @@ struct hrn_ctx {
         xs = outs;
     }
 
+    // PoseResNet (models_/poseresnet.py:16-122, Bottleneck sizes): 7x7 stem, max-pool, four ResNet layers on the
+    // generic / LDS-staged conv kernels, three ConvTranspose2d + BN + ReLU as four 3x3 phase convolutions each, head
+    void build_plan_poseresnet() {
+        static const int spec50[4] = {3, 4, 6, 3}, spec101[4] = {3, 4, 23, 3}, spec152[4] = {3, 8, 36, 3};
+        const int *layers = c == 50 ? spec50 : c == 101 ? spec101 : spec152;
+        stem_out_t = new_tensor(64, H / 2, W / 2);
+        ops.push_back({OP_STEM7, 0});
+        int x = new_tensor(64, H / 4, W / 4);
+        pool_in_t = stem_out_t, pool_out_t = x;
+        ops.push_back({OP_MAXPOOL, 0});
+        release(stem_out_t);
+        char buf[96];
+        for (int li = 0; li < 4; ++li) {
+            const int planes = 64 << li;
+            for (int b = 0; b < layers[li]; ++b) {
+                snprintf(buf, sizeof buf, "layer%d.%d", li + 1, b);
+                const std::string p = buf;
+                const int stride = (b == 0 && li > 0) ? 2 : 1;
+                int r = x;
+                const int o1 = add_conv(p + ".conv1", p + ".bn1", x, planes, 1, 1, 1, -1, false);
+                std::vector<int> first{(int)convs.size() - 1};
+                if (b == 0) {  // projection shortcut (poseresnet.py:53-59): reads x like conv1
+                    r = add_conv(p + ".downsample.0", p + ".downsample.1", x, planes * 4, 1, stride, 0, -1, false);
+                    first.push_back((int)convs.size() - 1);
+                }
+                emit_convs(first);
+                const int o2 = add_conv(p + ".conv2", p + ".bn2", o1, planes, 3, stride, 1);
+                const int o3 = add_conv(p + ".conv3", p + ".bn3", o2, planes * 4, 1, 1, 1, r);
+                release(o1), release(o2);
+                if (b == 0) release(r);
+                release(x);
+                x = o3;
+            }
+        }
+        for (int i = 0; i < 3; ++i) {  // deconv_layers: ConvTranspose2d(4, s2, p1) + BN + ReLU (poseresnet.py:84-104)
+            const Tensor tx = tensors[x];
+            const int up_t = new_tensor(256, tx.h * 2, tx.w * 2);
+            snprintf(buf, sizeof buf, "deconv_layers.%d", 3 * i);
+            const std::string cn = buf;
+            snprintf(buf, sizeof buf, "deconv_layers.%d", 3 * i + 1);
+            const std::string bn = buf;
+            std::vector<int> phases;
+            for (int ph = 0; ph < 4; ++ph) {
+                add_conv(cn, bn, x, 256, 3, 1, 1, -1, false, 0, 1 + ph, up_t);
+                phases.push_back((int)convs.size() - 1);
+            }
+            emit_convs(phases);
+            release(x);
+            x = up_t;
+        }
+        head_in_t = x;
+        head_c = tensors[x].c;
+        ops.push_back({OP_HEAD, 0});
+        ops.push_back({OP_DECODE, 0});
+        layout_blob();
+    }
+
     void build_plan() {
+        if (model == 1) return build_plan_poseresnet();
+        head_c = c;
         const int kc_dummy = 0;
         (void)kc_dummy;
         // stem conv1 (dedicated kernel), hrnet.py:158-160
@@ -452,9 +516,13 @@ struct hrn_ctx {
         ops.push_back({OP_HEAD, 0});
         ops.push_back({OP_DECODE, 0});
 
+        layout_blob();
+    }
+
+    void layout_blob() {
         // weight blob layout
         int64_t off = 0;
-        stem_w_off = off, off = align_up(off + 27 * 64 * 4, 256);
+        stem_w_off = off, off = align_up(off + (model == 1 ? 147 : 27) * 64 * 4, 256);  // PoseResNet: 7x7 stem
         stem_b_off = off, off = align_up(off + 64 * 4, 256);
         stem_wp_off = off, off = align_up(off + 4 * 1024, 256);  // bf16 MFMA image of conv1 (stem_mfma_kernel)
         for (auto &cv : convs) {
@@ -465,9 +533,9 @@ struct hrn_ctx {
             cv.b_off = off;
             off = align_up(off + cv.cout * 4, 256);
         }
-        head_w_off = off, off = align_up(off + (int64_t)joints * c * 4, 256);
+        head_w_off = off, off = align_up(off + (int64_t)joints * head_c * 4, 256);
         head_b_off = off, off = align_up(off + joints * 4, 256);
-        head_wp_off = off, off = align_up(off + 2 * ((c + 31) / 32) * 1024, 256);  // bf16 MFMA image (head_mfma_kernel)
+        head_wp_off = off, off = align_up(off + 2 * ((head_c + 31) / 32) * 1024, 256);  // bf16 MFMA image (head_mfma_kernel)
         blob_bytes = off;
 
         const int hw = (H / 4) * (W / 4);
@@ -592,8 +660,11 @@ struct hrn_ctx {
         return (int)ents.size();
     }
 
+    // the pixel grid a convolution iterates over: its output, or for a transposed-conv phase its input
+    const Tensor &grid_of(const ConvOp &cv) const { return tensors[cv.up ? cv.in_t : cv.out_t]; }
+
     ConvArgs conv_args(const ConvOp &cv, int nb, bool rev) const {
-        const Tensor &ti = tensors[cv.in_t], &to = tensors[cv.out_t];
+        const Tensor &ti = tensors[cv.in_t], &to = grid_of(cv);
         ConvArgs a;
         a.in = row0(cv.in_t), a.out = row0(cv.out_t);
         a.w = blob + cv.w_off, a.bias = (const float *)(blob + cv.b_off);
@@ -604,6 +675,8 @@ struct hrn_ctx {
         a.m = nb * to.hpwp;
         a.ksize = cv.k, a.stride = cv.stride, a.relu = cv.relu, a.kchunks = cv.kchunks;
         a.rev = rev;
+        a.up = cv.up ? 1 : 0, a.up_a = cv.up ? (cv.up - 1) >> 1 : 0, a.up_b = cv.up ? (cv.up - 1) & 1 : 0;
+        a.up_wp = tensors[cv.out_t].wp, a.up_hpwp = tensors[cv.out_t].hpwp;
         return a;
     }
 
@@ -626,13 +699,13 @@ struct hrn_ctx {
                 if (cls[ci].in_t == cv.in_t && cls[ci].k == cv.k && cls[ci].stride == cv.stride) break;
             if (ci == cls.size()) cls.push_back(Cls{cv.in_t, cv.k, cv.stride, {}, 0});
             cls[ci].members.push_back((int)k);
-            cls[ci].cost += (double)tensors[cv.out_t].hpwp * (cv.cout / (16 * g.nr)) * cv.kchunks;
+            cls[ci].cost += (double)grid_of(cv).hpwp * (cv.cout / (16 * g.nr)) * cv.kchunks;
         }
         std::stable_sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.cost > b.cost; });
         int n = 0;
         if (out) out->clear();
         for (const Cls &cl : cls) {
-            const int mtiles = (nb * tensors[convs[g.conv_idx[cl.members[0]]].out_t].hpwp + 64 * mr - 1) / (64 * mr);
+            const int mtiles = (nb * grid_of(convs[g.conv_idx[cl.members[0]]]).hpwp + 64 * mr - 1) / (64 * mr);
             for (int round = 0; round * 8 < mtiles; ++round)
                 for (int k : cl.members) {
                     const int ngroups = convs[g.conv_idx[k]].cout / (16 * g.nr);
@@ -774,8 +847,15 @@ struct hrn_ctx {
         }
         std::vector<char> host((size_t)blob_bytes, 0);
         std::vector<double> scale, shift;
-        // stem: w[k = ci*9+kh*3+kw][co]
-        {
+        if (model == 1) {  // PoseResNet stem: w[k = (ci*7 + kh)*7 + kw][co]
+            const float *w;
+            if (!lookup(m, "conv1.weight", 64 * 147, &w) || !bn_fold(m, "bn1", 64, scale, shift)) return false;
+            float *dw = (float *)(host.data() + stem_w_off), *db = (float *)(host.data() + stem_b_off);
+            for (int co = 0; co < 64; ++co) {
+                for (int k = 0; k < 147; ++k) dw[k * 64 + co] = (float)((double)w[co * 147 + k] * scale[co]);
+                db[co] = (float)shift[co];
+            }
+        } else {  // stem: w[k = ci*9+kh*3+kw][co]
             const float *w;
             if (!lookup(m, "conv1.weight", 64 * 27, &w) || !bn_fold(m, "bn1", 64, scale, shift)) return false;
             float *dw = (float *)(host.data() + stem_w_off), *db = (float *)(host.data() + stem_b_off);
@@ -800,6 +880,30 @@ struct hrn_ctx {
         for (auto &cv : convs) {
             const float *w;
             const int kk = cv.k * cv.k, K = kk * cv.cin;
+            if (cv.up) {
+                // phase (a, b) of ConvTranspose2d(cin, cout, 4, stride 2, padding 1), weight [ci][co][ky][kx]:
+                // out(2y + a, 2x + b) = sum over input (y + dy, x + dx) with ky = a + 1 - 2*dy in [0, 4), i.e.
+                // a = 0: (dy 0, ky 1), (dy -1, ky 3);  a = 1: (dy +1, ky 0), (dy 0, ky 2) -- the same along x.
+                if (!lookup(m, cv.conv + ".weight", (int64_t)cv.cin * cv.cout * 16, &w) ||
+                    !bn_fold(m, cv.bn, cv.cout, scale, shift))
+                    return false;
+                const int a = (cv.up - 1) >> 1, b = (cv.up - 1) & 1;
+                wf.assign((size_t)cv.cout * K, 0.f);
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int ky = a + 1 - 2 * dy, kx = b + 1 - 2 * dx;
+                        if (ky < 0 || ky > 3 || kx < 0 || kx > 3) continue;
+                        const int t = (dy + 1) * 3 + (dx + 1);
+                        for (int co = 0; co < cv.cout; ++co)
+                            for (int ci = 0; ci < cv.cin; ++ci)
+                                wf[(size_t)co * K + t * cv.cin + ci] =
+                                    (float)((double)w[(((size_t)ci * cv.cout + co) * 4 + ky) * 4 + kx] * scale[co]);
+                    }
+                pack_conv(cv, wf.data(), K, host.data() + cv.w_off);
+                float *db = (float *)(host.data() + cv.b_off);
+                for (int co = 0; co < cv.cout; ++co) db[co] = (float)shift[co];
+                continue;
+            }
             if (!lookup(m, cv.conv + ".weight", (int64_t)cv.cout * K, &w) ||
                 !bn_fold(m, cv.bn, cv.cout, scale, shift))
                 return false;
@@ -819,6 +923,7 @@ struct hrn_ctx {
         }
         {
             const float *w, *b;
+            const int c = head_c;  // channels final_layer reads
             if (!lookup(m, "final_layer.weight", (int64_t)joints * c, &w) || !lookup(m, "final_layer.bias", joints, &b))
                 return false;
             memcpy(host.data() + head_w_off, w, sizeof(float) * joints * c);
@@ -924,6 +1029,26 @@ struct hrn_ctx {
                     a.out_h = t.h, a.out_w = t.w, a.out_wp = t.wp, a.out_hpwp = t.hpwp;
                     a.flip = flip;
                     e = launch_stem(dtype, a, s);
+                    break;
+                }
+                case OP_STEM7: {
+                    const Tensor &t = tensors[stem_out_t];
+                    Stem7Args a;
+                    a.images = images, a.out = row0(stem_out_t);
+                    a.w = (const float *)(blob + stem_w_off), a.bias = (const float *)(blob + stem_b_off);
+                    a.n = nb, a.H = H, a.W = W;
+                    a.out_h = t.h, a.out_w = t.w, a.out_wp = t.wp, a.out_hpwp = t.hpwp;
+                    a.flip = flip;
+                    e = launch_stem7(dtype, a, s);
+                    break;
+                }
+                case OP_MAXPOOL: {
+                    const Tensor &ti = tensors[pool_in_t], &to = tensors[pool_out_t];
+                    PoolArgs a;
+                    a.in = row0(pool_in_t), a.out = row0(pool_out_t);
+                    a.c = to.c, a.n = nb, a.in_wp = ti.wp, a.in_hpwp = ti.hpwp;
+                    a.out_h = to.h, a.out_w = to.w, a.out_wp = to.wp, a.out_hpwp = to.hpwp;
+                    e = launch_maxpool(dtype, a, s);
                     break;
                 }
                 case OP_CONV: {
@@ -1059,9 +1184,22 @@ const char *hrn_version(void) { return "hrnet_mi355 0.1 (gfx950)"; }
 
 int hrn_create(hrn_handle *out, int c, int nof_joints, int height, int width, int dtype, int max_batch,
                int device_id) {
+    return hrn_create_model(out, HRN_MODEL_HRNET, c, nof_joints, height, width, dtype, max_batch, device_id);
+}
+
+int hrn_create_model(hrn_handle *out, int model, int c, int nof_joints, int height, int width, int dtype, int max_batch,
+                     int device_id) {
     if (!out) return 1;
     *out = nullptr;
-    if (c < 16 || c % 16 != 0) {
+    if (model != HRN_MODEL_HRNET && model != HRN_MODEL_POSERESNET) {
+        g_create_error = "model must be HRN_MODEL_HRNET or HRN_MODEL_POSERESNET";
+        return 2;
+    }
+    if (model == HRN_MODEL_POSERESNET && c != 50 && c != 101 && c != 152) {
+        g_create_error = "PoseResNet: c is the ResNet size, 50 / 101 / 152 (the reference's 18 / 34 cannot run: modules.py:50)";
+        return 2;
+    }
+    if (model == HRN_MODEL_HRNET && (c < 16 || c % 16 != 0)) {
         g_create_error = "c must be a positive multiple of 16 (HRNet-W32 / W48)";
         return 2;
     }
@@ -1082,6 +1220,7 @@ int hrn_create(hrn_handle *out, int c, int nof_joints, int height, int width, in
         return 2;
     }
     std::unique_ptr<hrn_ctx> h(new hrn_ctx());
+    h->model = model;
     h->c = c, h->joints = nof_joints, h->H = height, h->W = width, h->dtype = dtype, h->max_batch = max_batch;
     h->device = device_id, h->plan_only = device_id < 0;
     h->esize = dtype == HRN_BF16 ? 2 : 4;
@@ -1315,9 +1454,9 @@ int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out) {
 
 double hrn_flops_per_crop(hrn_handle h) {
     if (!h) return 0;
-    double f = 2.0 * 64 * 27 * (h->H / 2) * (double)(h->W / 2);              // conv1
+    double f = 2.0 * 64 * (h->model == 1 ? 147 : 27) * (h->H / 2) * (double)(h->W / 2);   // conv1
     for (auto &cv : h->convs) f += cv.flops;
-    f += 2.0 * h->joints * h->c * (h->H / 4) * (double)(h->W / 4);           // final_layer
+    f += 2.0 * h->joints * h->head_c * (h->H / 4) * (double)(h->W / 4);      // final_layer
     return f;
 }
 
@@ -1358,7 +1497,7 @@ int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms
                 std::vector<double> wgt;
                 for (int ci : g.conv_idx) {
                     const ConvOp &cv = h->convs[ci];
-                    wgt.push_back((double)h->tensors[cv.out_t].hpwp * (cv.cout / (16 * g.nr)) * cv.kchunks);
+                    wgt.push_back((double)h->grid_of(cv).hpwp * (cv.cout / (16 * g.nr)) * cv.kchunks);
                     tot += wgt.back();
                 }
                 for (size_t k = 0; k < g.conv_idx.size(); ++k)
@@ -1370,7 +1509,7 @@ int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms
                 if (conv_ms && ch.conv1 < conv_ms_len) conv_ms[ch.conv1] = share;
                 if (conv_ms && ch.ds >= 0 && ch.ds < conv_ms_len) conv_ms[ch.ds] = share;
             } else if (other_ms) {
-                const int slot = op.kind == OP_STEM ? 0 : op.kind == OP_FUSE ? 1 : op.kind == OP_HEAD ? 2 : 3;
+                const int slot = (op.kind == OP_STEM || op.kind == OP_STEM7 || op.kind == OP_MAXPOOL) ? 0 : op.kind == OP_FUSE ? 1 : op.kind == OP_HEAD ? 2 : 3;
                 other_ms[slot] += ms;
             }
         }

@@ -26,6 +26,9 @@ struct ConvArgs {
     int ksize, stride, relu;
     int kchunks;                            // padded K / (32 bf16 | 16 f32)
     int rev;                                // walk the M tiles backwards (see hrn_ctx::alternate)
+    // one phase (a, b) of a ConvTranspose2d(4, stride 2, padding 1) run as a 3x3 conv on the input grid: the result of
+    // pixel (ho, wo) is stored at (2*ho + a, 2*wo + b) of the twice-as-large tensor (poseresnet.py:84-100)
+    int up, up_a, up_b, up_wp, up_hpwp;
 };
 
 // LDS-staged 3x3 stride-1 convolution (conv3x3_lds.hip); input and output share one geometry.
@@ -87,6 +90,25 @@ struct CropParams {
 };
 hipError_t launch_prepath(const unsigned char *frame_dev, int frame_w, const CropParams *crops_dev, int n, int max_h_pad,
                           unsigned char *tmp_dev, float *images_dev, int H, int W, hipStream_t s);
+
+struct Stem7Args {         // PoseResNet conv1: 3->64 7x7 s2 p3 + BN + ReLU, NCHW fp32 in, flat padded out (poseresnet.py:25-27)
+    const float *images;
+    void *out;
+    const float *w;        // [147][64] fp32, folded, k = (ci*7 + kh)*7 + kw
+    const float *bias;     // [64]
+    int n, H, W;
+    int out_h, out_w, out_wp, out_hpwp;
+    int flip;
+};
+struct PoolArgs {          // MaxPool2d(3, stride 2, padding 1) on a post-ReLU tensor (poseresnet.py:28): zero pads == -inf pads
+    const void *in;
+    void *out;
+    int c, n;
+    int in_wp, in_hpwp;
+    int out_h, out_w, out_wp, out_hpwp;
+};
+hipError_t launch_stem7(int dtype, const Stem7Args &a, hipStream_t s);
+hipError_t launch_maxpool(int dtype, const PoolArgs &a, hipStream_t s);
 
 struct FuseTerm {
     const void *ptr;

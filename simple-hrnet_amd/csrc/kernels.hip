@@ -173,7 +173,11 @@ __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng
         const int rem = q % p.out_hpwp;
         const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
         const bool ok = (ho < p.out_h) && (wo < p.out_w);
-        const size_t o = (size_t)q * p.cout + ch0;
+        size_t o = (size_t)q * p.cout + ch0;
+        if (p.up) {  // transposed-conv phase: scatter to (2*ho + a, 2*wo + b); pad pixels of the phase grid write nothing
+            if (!ok) continue;
+            o = ((size_t)(q / p.out_hpwp) * p.up_hpwp + (size_t)(2 * ho + p.up_a) * p.up_wp + 2 * wo + p.up_b) * p.cout + ch0;
+        }
         if constexpr (DT == DT_BF16 && (NR % 2 == 0)) {
             // 8 contiguous channels per access: 16-byte residual loads and stores
 #pragma unroll
@@ -360,6 +364,107 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs p) {
             *(typename T::vec *)(o + cg * 16 + v * T::VEC) = ov;
         }
     }
+}
+
+// PoseResNet conv1: 3->64, 7x7, stride 2, pad 3 (+folded BN, ReLU) from the caller's NCHW fp32 batch.  fp32 fma chain in
+// both modes (k = (ci, kh, kw) ascending, starting at the bias); one thread = one output pixel, 16 channels at a time
+// (the weights are wave-uniform: scalar loads), the 147 inputs re-read from L1 for each of the four channel groups.
+template <int DT>
+__global__ __launch_bounds__(256) void stem7_kernel(const Stem7Args p) {
+    using T = Tr<DT>;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int m = p.n * p.out_hpwp;
+    if (q >= m) return;
+    const int n = q / p.out_hpwp, rem = q - n * p.out_hpwp;
+    const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
+    const bool ok = ho < p.out_h && wo < p.out_w;
+    const float *img = p.images + (size_t)n * 3 * p.H * p.W;
+    typename T::elem *o = (typename T::elem *)p.out + (size_t)q * 64;
+    for (int cg = 0; cg < 4; ++cg) {
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = p.bias[cg * 16 + c];
+        if (ok) {
+            for (int ci = 0; ci < 3; ++ci)
+                for (int kh = 0; kh < 7; ++kh) {
+                    const int iy = 2 * ho + kh - 3;
+                    if (iy < 0 || iy >= p.H) continue;  // zero padding: the term vanishes
+#pragma unroll
+                    for (int kw = 0; kw < 7; ++kw) {
+                        const int ix = 2 * wo + kw - 3;
+                        if (ix < 0 || ix >= p.W) continue;
+                        const float x = img[((size_t)ci * p.H + iy) * p.W + (p.flip ? p.W - 1 - ix : ix)];
+                        const float *wk = p.w + ((ci * 7 + kh) * 7 + kw) * 64 + cg * 16;
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) acc[c] = fmaf(x, wk[c], acc[c]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int v = 0; v < 16 / T::VEC; ++v) {
+            typename T::vec ov;
+#pragma unroll
+            for (int r = 0; r < T::VEC; ++r) ov[r] = T::st(ok ? fmaxf(acc[v * T::VEC + r], 0.f) : 0.f);
+            *(typename T::vec *)(o + cg * 16 + v * T::VEC) = ov;
+        }
+    }
+}
+
+hipError_t launch_stem7(int dtype, const Stem7Args &a, hipStream_t s) {
+    const int m = a.n * a.out_hpwp;
+    if (m <= 0) return hipSuccess;
+    dim3 grid((m + 255) / 256);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(stem7_kernel<DT_BF16>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(stem7_kernel<DT_F32>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// MaxPool2d(kernel 3, stride 2, padding 1) on the flat padded layout.  Its input is post-ReLU (>= 0) and the layout's
+// pad pixels are zeros, so a zero pad gives the same maximum as PyTorch's implicit -inf pad.
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs p) {
+    using T = Tr<DT>;
+    using vec = typename T::vec;
+    const int cvn = p.c / T::VEC;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)p.n * p.out_hpwp * cvn;
+    if (idx >= total) return;
+    const int q = (int)(idx / cvn), cv = (int)(idx - (long)q * cvn);
+    const int n = q / p.out_hpwp, rem = q - n * p.out_hpwp;
+    const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
+    vec o = {};
+    if (ho < p.out_h && wo < p.out_w) {
+        float best[T::VEC];
+#pragma unroll
+        for (int e = 0; e < T::VEC; ++e) best[e] = 0.f;   // >= every pad; inputs are >= 0
+        const typename T::elem *base = (const typename T::elem *)p.in + (size_t)cv * T::VEC;
+#pragma unroll
+        for (int dh = -1; dh <= 1; ++dh)
+#pragma unroll
+            for (int dw = -1; dw <= 1; ++dw) {
+                // row -1 / column -1 are pad (or guard) rows of the flat layout: zeros
+                const long row = (long)n * p.in_hpwp + (long)(2 * ho + dh) * p.in_wp + (2 * wo + dw);
+                const vec v = *(const vec *)(base + row * p.c);
+#pragma unroll
+                for (int e = 0; e < T::VEC; ++e) best[e] = fmaxf(best[e], T::ld((typename T::elem)v[e]));
+            }
+#pragma unroll
+        for (int e = 0; e < T::VEC; ++e) o[e] = T::st(best[e]);
+    }
+    *(vec *)((typename T::elem *)p.out + (size_t)q * p.c + (size_t)cv * T::VEC) = o;
+}
+
+hipError_t launch_maxpool(int dtype, const PoolArgs &a, hipStream_t s) {
+    const long total = (long)a.n * a.out_hpwp * (a.c / (dtype == DT_BF16 ? 8 : 4));
+    if (total <= 0) return hipSuccess;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(maxpool_kernel<DT_BF16>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<DT_F32>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 // bf16 mode: the same 3->64 stride-2 convolution on MFMA.  K = 27 (ci, kh, kw) padded to one 32-wide chunk; a

@@ -41,9 +41,16 @@ class NativeHRNet:
     """
 
     def __init__(self, c: int = 48, nof_joints: int = 17, resolution: Tuple[int, int] = (384, 288),
-                 dtype: Union[str, torch.dtype] = "bf16", max_batch: int = 32, device=0):
+                 dtype: Union[str, torch.dtype] = "bf16", max_batch: int = 32, device=0, model_name: str = "HRNet"):
         if dtype not in DTYPES:
             raise ValueError("dtype must be 'bf16' or 'fp32'")
+        if model_name in ("HRNet", "hrnet"):            # SimpleHRNet.py:109-112
+            model = 0
+        elif model_name in ("PoseResNet", "poseresnet", "ResNet", "resnet"):
+            model = 1                                  # c = ResNet size (50 / 101 / 152)
+        else:
+            raise ValueError("Wrong model name.")
+        self.model_name = "HRNet" if model == 0 else "PoseResNet"
         self.c, self.nof_joints = int(c), int(nof_joints)
         self.resolution = (int(resolution[0]), int(resolution[1]))
         self.dtype = "bf16" if DTYPES[dtype] == 1 else "fp32"
@@ -51,8 +58,8 @@ class NativeHRNet:
         self.device_index = -1 if (isinstance(device, int) and device < 0) else _device_index(device)
         self._lib = _lib.load()
         self._h = ctypes.c_void_p()
-        rc = self._lib.hrn_create(ctypes.byref(self._h), self.c, self.nof_joints, self.resolution[0],
-                                  self.resolution[1], DTYPES[dtype], self.max_batch, self.device_index)
+        rc = self._lib.hrn_create_model(ctypes.byref(self._h), model, self.c, self.nof_joints, self.resolution[0],
+                                        self.resolution[1], DTYPES[dtype], self.max_batch, self.device_index)
         if rc != 0:
             msg = self._lib.hrn_last_error(None).decode()
             self._h = ctypes.c_void_p()

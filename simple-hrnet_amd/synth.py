@@ -99,26 +99,59 @@ def hrnet_state_spec(c: int = 48, nof_joints: int = 17) -> List[Tuple[str, Tuple
     return s
 
 
+RESNET_SPEC = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}  # poseresnet.py:6-12 (Bottleneck sizes)
+
+
+def poseresnet_state_spec(resnet_size: int = 50, nof_joints: int = 17) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(key, shape, kind) for every entry of ``PoseResNet(resnet_size, nof_joints).state_dict()``
+    (models_/poseresnet.py:16-122; Bottleneck of models_/modules.py:5-40).  Sizes 18 / 34 are not offered: the
+    reference's ``BasicBlock`` builds ``conv2`` with ``inplanes`` input channels (modules.py:50) and fails at
+    run time as soon as a layer changes width."""
+    layers = RESNET_SPEC[resnet_size]
+    s: List[Tuple[str, Tuple[int, ...], str]] = []
+    s += _conv("conv1", 64, 3, 7) + _bn("bn1", 64)
+    inplanes = 64
+    for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), layers)):
+        for b in range(blocks):
+            p = "layer%d.%d" % (li + 1, b)
+            s += _conv(p + ".conv1", planes, inplanes, 1) + _bn(p + ".bn1", planes)
+            s += _conv(p + ".conv2", planes, planes, 3) + _bn(p + ".bn2", planes)
+            s += _conv(p + ".conv3", planes * 4, planes, 1) + _bn(p + ".bn3", planes * 4)
+            if b == 0:  # stride != 1 or inplanes != planes * 4 (poseresnet.py:53-59)
+                s += _conv(p + ".downsample.0", planes * 4, inplanes, 1) + _bn(p + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+    for i in range(3):  # ConvTranspose2d(in, 256, 4, stride 2, padding 1, bias=False) + BN + ReLU
+        s += [("deconv_layers.%d.weight" % (3 * i), (inplanes, 256, 4, 4), "deconv")] + _bn("deconv_layers.%d" % (3 * i + 1), 256)
+        inplanes = 256
+    s += [("final_layer.weight", (nof_joints, 256, 1, 1), "conv"), ("final_layer.bias", (nof_joints,), "conv_bias")]
+    return s
+
+
 def _rng_for(seed: int, key: str) -> np.random.Generator:
     # one independent stream per tensor, keyed by name: order-independent
     return np.random.default_rng([seed, zlib.crc32(key.encode())])
 
 
-def synth_state_dict(c: int = 48, nof_joints: int = 17, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
-    """Seeded checkpoint as numpy arrays (fp32; ``num_batches_tracked`` int64).
+def synth_state_dict(c: int = 48, nof_joints: int = 17, seed: int = 0, model: str = "HRNet") -> "OrderedDict[str, np.ndarray]":
+    """Seeded checkpoint as numpy arrays (fp32; ``num_batches_tracked`` int64).  ``model="PoseResNet"``: ``c`` is
+    the ResNet size (50 / 101 / 152).
 
     conv: U(-b, b), b = 1/sqrt(fan_in)  (the bound torch's default Conv2d init uses)
     BN:   gamma ~ U(0.5,1.5), beta ~ N(0,0.1), mean ~ N(0,0.1), var ~ U(0.5,1.5)
     """
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
-    for key, shape, kind in hrnet_state_spec(c, nof_joints):
+    spec = hrnet_state_spec(c, nof_joints) if model in ("HRNet", "hrnet") else poseresnet_state_spec(c, nof_joints)
+    for key, shape, kind in spec:
         g = _rng_for(seed, key)
-        if kind == "conv":
+        if kind == "deconv":   # (cin, cout, 4, 4): every output sees cin x 2 x 2 taps
+            b = 1.0 / np.sqrt(shape[0] * 4)
+            a = g.uniform(-b, b, size=shape)
+        elif kind == "conv":
             fan_in = shape[1] * shape[2] * shape[3]
             b = 1.0 / np.sqrt(fan_in)
             a = g.uniform(-b, b, size=shape)
         elif kind == "conv_bias":
-            b = 1.0 / np.sqrt(c)
+            b = 1.0 / np.sqrt(c if model in ("HRNet", "hrnet") else 256)
             a = g.uniform(-b, b, size=shape)
         elif kind == "bn_gamma":
             a = g.uniform(0.5, 1.5, size=shape)

@@ -260,9 +260,26 @@ def flip_tta_case(name, c, n, h, w, seed=0):
          preds_nopost=preds_raw.numpy(), maxvals=maxvals.numpy(), flip_pairs=np.asarray(COCO_FLIP_PAIRS, np.int32))
 
 
+def poseresnet_case(name, size, n, h, w, seed=0):
+    """models_/poseresnet.py PoseResNet, imported unmodified, on seeded synthetic weights."""
+    from models_.poseresnet import PoseResNet
+
+    m = PoseResNet(size, 17).eval()
+    m.load_state_dict(synth.to_torch_state_dict(synth.synth_state_dict(size, 17, seed, model="PoseResNet")))
+    x = synth.synth_crops(n, h, w, seed=17)
+    with torch.no_grad():
+        y = m(torch.from_numpy(x)).numpy()
+    boxes = synth.synth_boxes(n)
+    save(name, c=size, n=n, h=h, w=w, weight_seed=seed, crops=x, heatmaps=y, boxes=boxes,
+         pts=ref_decode(y, boxes, h // 4, w // 4))
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     yolo = install_stubs()
+    if len(sys.argv) > 1 and sys.argv[1] == "poseresnet":
+        poseresnet_case("poseresnet50_128x96_n2", 50, 2, 128, 96, seed=3)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fliptta":   # only the flip-TTA fixture
         flip_tta_case("w32_128x96_fliptta_n3", 32, 3, 128, 96, seed=2)
         return
@@ -272,6 +289,7 @@ def main():
     heatmap_case("w48_384x288_n1", 48, 1, 384, 288)
     predict_cases(yolo)
     flip_tta_case("w32_128x96_fliptta_n3", 32, 3, 128, 96, seed=2)
+    poseresnet_case("poseresnet50_128x96_n2", 50, 2, 128, 96, seed=3)
 
 
 if __name__ == "__main__":

@@ -6,9 +6,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--c", type=int, default=48); ap.add_argument("--height", type=int, default=384)
 ap.add_argument("--width", type=int, default=288); ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--mb", type=int, default=64); ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--model-name", default="HRNet")
 a = ap.parse_args()
 pkg = importlib.import_module("simple-hrnet_amd")
-net = pkg.NativeHRNet(a.c, 17, (a.height, a.width), a.dtype, max_batch=a.mb, device=0).load_state_dict(pkg.synth_state_dict(a.c, 17, 0))
+net = pkg.NativeHRNet(a.c, 17, (a.height, a.width), a.dtype, max_batch=a.mb, device=0, model_name=a.model_name).load_state_dict(pkg.synth_state_dict(a.c, 17, 0, model=a.model_name))
 x = torch.randn((a.mb, 3, a.height, a.width), device="cuda")
 infos = net.conv_infos()
 acc = None
