@@ -46,7 +46,7 @@ typedef struct {
 /* Static description of one convolution of the compiled graph (for tests / tooling). */
 typedef struct {
     char name[96];        /* state_dict prefix of the conv, e.g. "stage3.1.branches.2.0.conv1" */
-    int32_t cin, cout, ksize, stride, relu, has_residual;
+    int32_t cin, cout, ksize, stride, relu, has_residual;   /* ksize 2 = one phase of a ConvTranspose2d(4, s2, p1) */
     int32_t in_h, in_w, out_h, out_w;
     int32_t kpad;         /* K = ksize*ksize*cin rounded up to the MFMA K-chunk                 */
     int32_t nr;           /* 16-wide cout fragments per group (packing parameter)              */

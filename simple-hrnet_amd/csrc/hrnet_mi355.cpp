@@ -217,7 +217,7 @@ struct hrn_ctx {
         op.kchunks = (K + kc - 1) / kc;
         op.kpad = op.kchunks * kc;
         op.nr = nr_override ? nr_override : default_nr(cout, stride);
-        op.flops = 2.0 * cout * (double)(up ? 4 * op.cin : K) * oh * ow;  // a transposed-conv phase has 4 live taps of the 9
+        op.flops = 2.0 * cout * (double)K * oh * ow;
         // pipelined LDS kernel (conv3x3_lds.hip): KS = 48 / 48-cout tiles for the HRNet-W48 branch widths, KS = 32 with
         // 64-, 48- or 32-cout tiles for everything else whose channel counts are multiples of 32
         int lds_ks = 0, lds_nrb = 0;
@@ -431,7 +431,7 @@ struct hrn_ctx {
             const std::string bn = buf;
             std::vector<int> phases;
             for (int ph = 0; ph < 4; ++ph) {
-                add_conv(cn, bn, x, 256, 3, 1, 1, -1, false, 0, 1 + ph, up_t);
+                add_conv(cn, bn, x, 256, 2, 1, 1, -1, false, 0, 1 + ph, up_t);  // k = 2: the four live taps of the phase
                 phases.push_back((int)convs.size() - 1);
             }
             emit_convs(phases);
@@ -524,7 +524,7 @@ struct hrn_ctx {
         int64_t off = 0;
         stem_w_off = off, off = align_up(off + (model == 1 ? 147 : 27) * 64 * 4, 256);  // PoseResNet: 7x7 stem
         stem_b_off = off, off = align_up(off + 64 * 4, 256);
-        stem_wp_off = off, off = align_up(off + 4 * 1024, 256);  // bf16 MFMA image of conv1 (stem_mfma_kernel)
+        stem_wp_off = off, off = align_up(off + (model == 1 ? 5 : 1) * 4 * 1024, 256);  // bf16 MFMA image of conv1 (stem_mfma_kernel / stem7_mfma_kernel)
         for (auto &cv : convs) {
             cv.w_off = off;
             cv.w_bytes = cv.algo == 1 ? (int64_t)cv.ntiles * cv.slices * cv.nch * cv.nr * 1024
@@ -677,6 +677,10 @@ struct hrn_ctx {
         a.rev = rev;
         a.up = cv.up ? 1 : 0, a.up_a = cv.up ? (cv.up - 1) >> 1 : 0, a.up_b = cv.up ? (cv.up - 1) & 1 : 0;
         a.up_wp = tensors[cv.out_t].wp, a.up_hpwp = tensors[cv.out_t].hpwp;
+        for (int t = 0; t < 4; ++t) {  // live tap t = ty*2 + tx of phase (a, b): dy = ty - 1 + a, dx = tx - 1 + b
+            const int dy = (t >> 1) - 1 + a.up_a, dx = (t & 1) - 1 + a.up_b;
+            a.taps[t] = cv.up ? dy * ti.wp + dx : 0;
+        }
         return a;
     }
 
@@ -855,6 +859,19 @@ struct hrn_ctx {
                 for (int k = 0; k < 147; ++k) dw[k * 64 + co] = (float)((double)w[co * 147 + k] * scale[co]);
                 db[co] = (float)shift[co];
             }
+            // MFMA image: five K chunks (k = (ci*7 + kh)*7 + kw, zero for k >= 147), 4 fragments, cout permutation NR = 4
+            uint16_t *dp = (uint16_t *)(host.data() + stem_wp_off);
+            for (int kc = 0; kc < 5; ++kc)
+                for (int j = 0; j < 4; ++j)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int li = lane & 15, g = lane >> 4;
+                        const int co = (li >> 2) * 16 + j * 4 + (li & 3);
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = kc * 32 + g * 8 + e;
+                            dp[((kc * 4 + j) * 64 + lane) * 8 + e] =
+                                f32_to_bf16_host(k < 147 ? (float)((double)w[co * 147 + k] * scale[co]) : 0.f);
+                        }
+                    }
         } else {  // stem: w[k = ci*9+kh*3+kw][co]
             const float *w;
             if (!lookup(m, "conv1.weight", 64 * 27, &w) || !bn_fold(m, "bn1", 64, scale, shift)) return false;
@@ -888,17 +905,15 @@ struct hrn_ctx {
                     !bn_fold(m, cv.bn, cv.cout, scale, shift))
                     return false;
                 const int a = (cv.up - 1) >> 1, b = (cv.up - 1) & 1;
-                wf.assign((size_t)cv.cout * K, 0.f);
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int ky = a + 1 - 2 * dy, kx = b + 1 - 2 * dx;
-                        if (ky < 0 || ky > 3 || kx < 0 || kx > 3) continue;
-                        const int t = (dy + 1) * 3 + (dx + 1);
-                        for (int co = 0; co < cv.cout; ++co)
-                            for (int ci = 0; ci < cv.cin; ++ci)
-                                wf[(size_t)co * K + t * cv.cin + ci] =
-                                    (float)((double)w[(((size_t)ci * cv.cout + co) * 4 + ky) * 4 + kx] * scale[co]);
-                    }
+                wf.assign((size_t)cv.cout * K, 0.f);   // K = 4*cin: live tap t = ty*2 + tx, dy = ty - 1 + a, dx = tx - 1 + b
+                for (int t = 0; t < 4; ++t) {
+                    const int dy = (t >> 1) - 1 + a, dx = (t & 1) - 1 + b;
+                    const int ky = a + 1 - 2 * dy, kx = b + 1 - 2 * dx;   // in [0, 4) by construction
+                    for (int co = 0; co < cv.cout; ++co)
+                        for (int ci = 0; ci < cv.cin; ++ci)
+                            wf[(size_t)co * K + t * cv.cin + ci] =
+                                (float)((double)w[(((size_t)ci * cv.cout + co) * 4 + ky) * 4 + kx] * scale[co]);
+                }
                 pack_conv(cv, wf.data(), K, host.data() + cv.w_off);
                 float *db = (float *)(host.data() + cv.b_off);
                 for (int co = 0; co < cv.cout; ++co) db[co] = (float)shift[co];
@@ -1036,6 +1051,7 @@ struct hrn_ctx {
                     Stem7Args a;
                     a.images = images, a.out = row0(stem_out_t);
                     a.w = (const float *)(blob + stem_w_off), a.bias = (const float *)(blob + stem_b_off);
+                    a.wp = (dtype == HRN_BF16 && !disable_stem_mfma) ? (const void *)(blob + stem_wp_off) : nullptr;
                     a.n = nb, a.H = H, a.W = W;
                     a.out_h = t.h, a.out_w = t.w, a.out_wp = t.wp, a.out_hpwp = t.hpwp;
                     a.flip = flip;

@@ -29,6 +29,7 @@ struct ConvArgs {
     // one phase (a, b) of a ConvTranspose2d(4, stride 2, padding 1) run as a 3x3 conv on the input grid: the result of
     // pixel (ho, wo) is stored at (2*ho + a, 2*wo + b) of the twice-as-large tensor (poseresnet.py:84-100)
     int up, up_a, up_b, up_wp, up_hpwp;
+    int taps[4];                            // ksize == 2: row shift of the four live taps (tap-major K = 4*cin)
 };
 
 // LDS-staged 3x3 stride-1 convolution (conv3x3_lds.hip); input and output share one geometry.
@@ -96,6 +97,7 @@ struct Stem7Args {         // PoseResNet conv1: 3->64 7x7 s2 p3 + BN + ReLU, NCH
     void *out;
     const float *w;        // [147][64] fp32, folded, k = (ci*7 + kh)*7 + kw
     const float *bias;     // [64]
+    const void *wp;        // bf16 mode: MFMA image [5 chunks][4 frags][64 lanes][8 bf16], K = 147 padded to 160
     int n, H, W;
     int out_h, out_w, out_wp, out_hpwp;
     int flip;

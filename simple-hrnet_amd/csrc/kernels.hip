@@ -140,6 +140,8 @@ __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng
             if (p.ksize == 3) {
                 const int dh = (tap * 11) >> 5, dw = tap - dh * 3;
                 tapoff = (dh - 1) * p.in_wp + (dw - 1);
+            } else if (p.ksize == 2) {  // the four live taps of a transposed-conv phase
+                tapoff = tap == 0 ? p.taps[0] : tap == 1 ? p.taps[1] : tap == 2 ? p.taps[2] : p.taps[3];
             }
             const long aoff = (long)tapoff * p.cin + ci;
 #pragma unroll
@@ -410,11 +412,85 @@ __global__ __launch_bounds__(256) void stem7_kernel(const Stem7Args p) {
     }
 }
 
+// bf16 mode: the 7x7 stem on MFMA.  K = 147 (ci, kh, kw) padded to five 32-wide chunks; a lane gathers its 8 k-values
+// of one output pixel per chunk straight from the NCHW fp32 crop (rounded to bf16), accumulators start at the bias.
+__global__ __launch_bounds__(256) void stem7_mfma_kernel(const Stem7Args p) {
+    constexpr int MR = 4, NR = 4, KCH = 5;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int m = p.n * p.out_hpwp;
+    const int q0 = (blockIdx.x * 4 + wave) * 64;
+    if (q0 >= m) return;
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const f32x4 b = *(const f32x4 *)(p.bias + g * 4 * NR + j * 4);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) acc[i][j] = b;
+    }
+    bool okp[MR];
+    int hy[MR], wx[MR];
+    const float *img[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int q = q0 + i * 16 + li;
+        const int n = q / p.out_hpwp, rem = q - n * p.out_hpwp;
+        const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
+        okp[i] = q < m && ho < p.out_h && wo < p.out_w;
+        hy[i] = 2 * ho - 3, wx[i] = 2 * wo - 3;
+        img[i] = p.images + (size_t)(q < m ? n : 0) * 3 * p.H * p.W;
+    }
+    for (int kc = 0; kc < KCH; ++kc) {
+        s16x8 wf[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) wf[j] = *(const s16x8 *)((const char *)p.wp + ((kc * NR + j) * 64 + lane) * 16);
+        int dci[8], dkh[8], dkw[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kc * 32 + g * 8 + e;
+            dci[e] = k / 49, dkh[e] = (k % 49) / 7, dkw[e] = k % 7;
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            s16x8 xf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int iy = hy[i] + dkh[e], ix = wx[i] + dkw[e];
+                float v = 0.f;
+                if (okp[i] && kc * 32 + g * 8 + e < 147 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                    v = img[i][((size_t)dci[e] * p.H + iy) * p.W + (p.flip ? p.W - 1 - ix : ix)];
+                xf[e] = (short)f32_to_bf16(v);
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) acc[i][j] = mma<DT_BF16>(wf[j], xf, acc[i][j]);
+        }
+    }
+    unsigned short *out = (unsigned short *)p.out;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int q = q0 + i * 16 + li;
+        if (q >= m) continue;
+        unsigned short *o = out + (size_t)q * 64 + g * 4 * NR;
+#pragma unroll
+        for (int j = 0; j < NR; j += 2) {
+            s16x8 o8;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float v = okp[i] ? fmaxf(acc[i][j + (r >> 2)][r & 3], 0.f) : 0.f;
+                o8[r] = (short)f32_to_bf16(v);
+            }
+            *(s16x8 *)(o + j * 4) = o8;
+        }
+    }
+}
+
 hipError_t launch_stem7(int dtype, const Stem7Args &a, hipStream_t s) {
     const int m = a.n * a.out_hpwp;
     if (m <= 0) return hipSuccess;
     dim3 grid((m + 255) / 256);
-    if (dtype == DT_BF16)
+    if (dtype == DT_BF16 && a.wp)
+        hipLaunchKernelGGL(stem7_mfma_kernel, grid, dim3(256), 0, s, a);
+    else if (dtype == DT_BF16)
         hipLaunchKernelGGL(stem7_kernel<DT_BF16>, grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(stem7_kernel<DT_F32>, grid, dim3(256), 0, s, a);
