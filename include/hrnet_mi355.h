@@ -131,6 +131,16 @@ int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, in
 int hrn_forward_flip_tta(hrn_handle h, const void *images_dev, int n, const int32_t *flip_pairs_host, int npairs,
                          int post_processing, float *heatmaps_dev, float *preds_dev, float *maxvals_dev, void *stream);
 
+/* Greedy IoU non-maximum suppression -- the reference's only native component:
+ * `void _nms(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, int boxes_dim, float thresh,
+ * int device_id)` (misc/nms/gpu_nms.hpp; kernel misc/nms/nms_kernel.cu:33-77, caller misc/nms/gpu_nms.pyx:19-34).
+ * Same contract: boxes sorted by score descending, rows [x1,y1,x2,y2,score,...], IoU with the +1 pixel convention,
+ * a box is dropped when its IoU with an earlier kept box is > thresh; keep_out receives the kept row indices in
+ * order, *num_out their count.  Needs no handle.  Returns 0 or an error code (hrn_nms_last_error()). */
+int hrn_nms(int32_t *keep_out, int32_t *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
+            float nms_overlap_thresh, int device_id);
+const char *hrn_nms_last_error(void);
+
 /* Introspection used by tests, bench.py and the roofline accounting. */
 int hrn_conv_count(hrn_handle h);
 int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out);

@@ -274,9 +274,42 @@ def poseresnet_case(name, size, n, h, w, seed=0):
          pts=ref_decode(y, boxes, h // 4, w // 4))
 
 
+def nms_boxes(n, seed, frame=(480, 640), crowd=True):
+    """random detections: a few clusters of heavily overlapping boxes (what NMS is for) + scattered ones; distinct scores"""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform([40, 40], [frame[1] - 40, frame[0] - 40], size=(max(1, n // 8), 2))
+    c = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 12 if crowd else 80, (n, 2))
+    wh = rng.uniform(20, 160, (n, 2))
+    d = np.concatenate([c - wh / 2, c + wh / 2, rng.permutation(n)[:, None] / n + 0.001], 1)
+    return d.astype(np.float32)
+
+
+def nms_case(name):
+    """misc/nms/nms.py:35-72 `nms`, imported unmodified (its compiled siblings cpu_nms / gpu_nms are not built here and
+    are only imported at module top, so empty stand-in modules satisfy the import)."""
+    for mod in ("cpu_nms", "gpu_nms"):
+        m = types.ModuleType(mod)
+        setattr(m, mod, None)
+        sys.modules[mod] = m
+    sys.path.insert(0, os.path.join(REF, "misc", "nms"))
+    import nms as ref_nms
+
+    arrays = {}
+    for i, (n, thr, seed) in enumerate([(1, 0.5, 0), (7, 0.5, 1), (64, 0.3, 2), (65, 0.7, 3), (300, 0.5, 4), (1000, 0.45, 5)]):
+        d = nms_boxes(n, seed)
+        arrays["dets%d" % i] = d
+        arrays["thresh%d" % i] = np.float32(thr)
+        arrays["keep%d" % i] = np.asarray(ref_nms.nms(d, thr), dtype=np.int32)
+    arrays["ncases"] = np.int32(6)
+    save(name, **arrays)
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     yolo = install_stubs()
+    if len(sys.argv) > 1 and sys.argv[1] == "nms":
+        nms_case("nms_cases")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "poseresnet":
         poseresnet_case("poseresnet50_128x96_n2", 50, 2, 128, 96, seed=3)
         return
@@ -290,6 +323,7 @@ def main():
     predict_cases(yolo)
     flip_tta_case("w32_128x96_fliptta_n3", 32, 3, 128, 96, seed=2)
     poseresnet_case("poseresnet50_128x96_n2", 50, 2, 128, 96, seed=3)
+    nms_case("nms_cases")
 
 
 if __name__ == "__main__":
