@@ -1,7 +1,8 @@
 """simple-hrnet_amd -- MI355X-native (gfx950 / CDNA4) HRNet pose-inference hot path.
 
 Drop-in for the model call + heat-map decode behind ``SimpleHRNet.predict()`` of
-stefanopini/simple-HRNet (SimpleHRNet.py:281-308): hand-written HIP kernels behind the C ABI in
+stefanopini/simple-HRNet (SimpleHRNet.py:281-308), plus its crop pre-path, flip-TTA evaluation decode, PoseResNet
+and box NMS: hand-written HIP kernels behind the C ABI in
 ``include/hrnet_mi355.h``; this package is the thin ctypes / torch-tensor shim around it.
 
 The directory name contains a hyphen (the name the project mandates), so import it with
@@ -11,6 +12,7 @@ at the repository root.
 from . import _lib  # noqa: F401
 from . import synth  # noqa: F401
 from .native import NativeHRNet  # noqa: F401
+from .nms import gpu_nms  # noqa: F401
 from .synth import synth_boxes, synth_crops, synth_state_dict  # noqa: F401
 
-__all__ = ["NativeHRNet", "synth", "synth_state_dict", "synth_crops", "synth_boxes"]
+__all__ = ["NativeHRNet", "gpu_nms", "synth", "synth_state_dict", "synth_crops", "synth_boxes"]
