@@ -388,6 +388,54 @@ struct hrn_ctx {
         xs = outs;
     }
 
+    // `nblocks` Bottlenecks of 64 planes on a 64-channel input at stride 1 ("layer1" of HRNet and of PoseResNet,
+    // modules.py:20-40): in bf16 conv3 of block b and conv1 of block b+1 share the chain kernel
+    int add_layer1(int x, int nblocks) {
+        char buf[96];
+        int o1_next = -1;  // conv1 output of the next Bottleneck when the previous one already produced it
+        for (int b = 0; b < nblocks; ++b) {
+            snprintf(buf, sizeof buf, "layer1.%d", b);
+            const std::string p = buf;
+            int o1 = o1_next, r = x;
+            const bool chain = dtype == HRN_BF16 && !disable_chain && b < nblocks - 1;
+            int ds_idx = -1;
+            if (b == 0 && chain && !disable_chain_ds) {
+                // the projection shortcut is computed inside the chain kernel: its 256-channel tensor never exists
+                o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1);
+                r = add_conv(p + ".downsample.0", p + ".downsample.1", x, 256, 1, 1, 0, -1, false, 2);
+                ds_idx = (int)convs.size() - 1;
+                release(r);  // never written: hand the buffer back at once
+            } else if (b == 0) {  // conv1 and the projection shortcut both read x: one launch
+                o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1, -1, false);
+                r = add_conv(p + ".downsample.0", p + ".downsample.1", x, 256, 1, 1, 0, -1, false);
+                emit_convs({(int)convs.size() - 2, (int)convs.size() - 1});
+            } else if (o1 < 0) {
+                o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1);
+            }
+            const int o2 = add_conv(p + ".conv2", p + ".bn2", o1, 64, 3, 1, 1);
+            int o3;
+            o1_next = -1;
+            if (chain) {
+                // conv3 (+shortcut, ReLU) of this block and conv1 (+ReLU) of the next in one pass: the 256-channel
+                // tensor is written once and never read back by a 1x1 conv (bottleneck_chain.hip)
+                snprintf(buf, sizeof buf, "layer1.%d", b + 1);
+                const std::string pn = buf;
+                o3 = add_conv(p + ".conv3", p + ".bn3", o2, 256, 1, 1, 1, r, false, 2);
+                const int i3 = (int)convs.size() - 1;
+                o1_next = add_conv(pn + ".conv1", pn + ".bn1", o3, 64, 1, 1, 1, -1, false, 4);
+                chains.push_back({i3, (int)convs.size() - 1, ds_idx});
+                ops.push_back({OP_CHAIN, (int)chains.size() - 1});
+            } else {
+                o3 = add_conv(p + ".conv3", p + ".bn3", o2, 256, 1, 1, 1, r);
+            }
+            release(o1), release(o2);
+            if (b == 0 && ds_idx < 0) release(r);
+            release(x);
+            x = o3;
+        }
+        return x;
+    }
+
     // PoseResNet (models_/poseresnet.py:16-122, Bottleneck sizes): 7x7 stem, max-pool, four ResNet layers on the
     // generic / LDS-staged conv kernels, three ConvTranspose2d + BN + ReLU as four 3x3 phase convolutions each, head
     void build_plan_poseresnet() {
@@ -400,7 +448,8 @@ struct hrn_ctx {
         ops.push_back({OP_MAXPOOL, 0});
         release(stem_out_t);
         char buf[96];
-        for (int li = 0; li < 4; ++li) {
+        x = add_layer1(x, layers[0]);
+        for (int li = 1; li < 4; ++li) {
             const int planes = 64 << li;
             for (int b = 0; b < layers[li]; ++b) {
                 snprintf(buf, sizeof buf, "layer%d.%d", li + 1, b);
@@ -456,47 +505,7 @@ struct hrn_ctx {
         int x = add_conv("conv2", "bn2", stem_out_t, 64, 3, 2, 1);  // hrnet.py:161-163
         release(stem_out_t);
         char buf[96];
-        int o1_next = -1;  // conv1 output of the next Bottleneck when the previous one already produced it
-        for (int b = 0; b < 4; ++b) {  // layer1: Bottleneck x4, modules.py:20-40
-            snprintf(buf, sizeof buf, "layer1.%d", b);
-            const std::string p = buf;
-            int o1 = o1_next, r = x;
-            const bool chain = dtype == HRN_BF16 && !disable_chain && b < 3;
-            int ds_idx = -1;
-            if (b == 0 && chain && !disable_chain_ds) {
-                // the projection shortcut is computed inside the chain kernel: its 256-channel tensor never exists
-                o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1);
-                r = add_conv(p + ".downsample.0", p + ".downsample.1", x, 256, 1, 1, 0, -1, false, 2);
-                ds_idx = (int)convs.size() - 1;
-                release(r);  // never written: hand the buffer back at once
-            } else if (b == 0) {  // conv1 and the projection shortcut both read x: one launch
-                o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1, -1, false);
-                r = add_conv(p + ".downsample.0", p + ".downsample.1", x, 256, 1, 1, 0, -1, false);
-                emit_convs({(int)convs.size() - 2, (int)convs.size() - 1});
-            } else if (o1 < 0) {
-                o1 = add_conv(p + ".conv1", p + ".bn1", x, 64, 1, 1, 1);
-            }
-            const int o2 = add_conv(p + ".conv2", p + ".bn2", o1, 64, 3, 1, 1);
-            int o3;
-            o1_next = -1;
-            if (chain) {
-                // conv3 (+shortcut, ReLU) of this block and conv1 (+ReLU) of the next in one pass: the 256-channel
-                // tensor is written once and never read back by a 1x1 conv (bottleneck_chain.hip)
-                snprintf(buf, sizeof buf, "layer1.%d", b + 1);
-                const std::string pn = buf;
-                o3 = add_conv(p + ".conv3", p + ".bn3", o2, 256, 1, 1, 1, r, false, 2);
-                const int i3 = (int)convs.size() - 1;
-                o1_next = add_conv(pn + ".conv1", pn + ".bn1", o3, 64, 1, 1, 1, -1, false, 4);
-                chains.push_back({i3, (int)convs.size() - 1, ds_idx});
-                ops.push_back({OP_CHAIN, (int)chains.size() - 1});
-            } else {
-                o3 = add_conv(p + ".conv3", p + ".bn3", o2, 256, 1, 1, 1, r);
-            }
-            release(o1), release(o2);
-            if (b == 0 && ds_idx < 0) release(r);
-            release(x);
-            x = o3;
-        }
+        x = add_layer1(x, 4);  // layer1: Bottleneck x4, modules.py:20-40
         std::vector<int> xs;
         xs.push_back(add_conv("transition1.0.0", "transition1.0.1", x, c, 3, 1, 1, -1, false));
         xs.push_back(add_conv("transition1.1.0.0", "transition1.1.0.1", x, 2 * c, 3, 2, 1, -1, false));
