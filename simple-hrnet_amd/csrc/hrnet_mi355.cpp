@@ -497,8 +497,6 @@ struct hrn_ctx {
     void build_plan() {
         if (model == 1) return build_plan_poseresnet();
         head_c = c;
-        const int kc_dummy = 0;
-        (void)kc_dummy;
         // stem conv1 (dedicated kernel), hrnet.py:158-160
         stem_out_t = new_tensor(64, H / 2, W / 2);
         ops.push_back({OP_STEM, 0});
