@@ -13,6 +13,7 @@ from . import _lib  # noqa: F401
 from . import synth  # noqa: F401
 from .native import NativeHRNet  # noqa: F401
 from .nms import gpu_nms  # noqa: F401
+from .simple_hrnet import SimpleHRNet  # noqa: F401
 from .synth import synth_boxes, synth_crops, synth_state_dict  # noqa: F401
 
-__all__ = ["NativeHRNet", "gpu_nms", "synth", "synth_state_dict", "synth_crops", "synth_boxes"]
+__all__ = ["NativeHRNet", "SimpleHRNet", "gpu_nms", "synth", "synth_state_dict", "synth_crops", "synth_boxes"]

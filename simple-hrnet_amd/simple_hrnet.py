@@ -1,0 +1,143 @@
+"""``SimpleHRNet`` with the reference's constructor and ``predict()`` contract (``SimpleHRNet.py:21-172, 174-496``) on
+top of the MI355X library -- what a user of the reference instantiates after switching.
+
+Same argument names and meaning, same return structure (numpy arrays: heat-maps float32, boxes int32 / float32, joints
+``(y, x, confidence)`` float32; lists per image for stacks), same error for a wrong model name or image rank.  What is
+different, and why:
+
+* the person detector is injected (``detector=``: an object with ``predict_single(image)`` / ``predict(images)``
+  returning ``(P, >=4)`` rows ``x1, y1, x2, y2, ...`` or ``None``) -- the reference's YOLOv3 wrapper depends on an
+  un-vendored third-party submodule (``models_/detectors/yolo``) and YOLOv5 on ``torch.hub`` (network);
+* ``multiperson=False`` needs frames that already have the model resolution: the reference resizes them with
+  ``cv2.resize(INTER_CUBIC)`` (``:213-218``), which cannot be pinned here (cv2 is absent);
+* ``dtype`` picks the arithmetic mode of the engine (``"fp32"`` = parity mode, ``"bf16"`` = MFMA bf16);
+* one GPU per process (``device='cuda:N'``); for several use ``dist.ShardedHRNet`` instead of ``DataParallel``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .native import NativeHRNet
+
+_MEAN = (0.485, 0.456, 0.406)   # SimpleHRNet.py:171
+_STD = (0.229, 0.224, 0.225)
+
+
+class SimpleHRNet:
+    def __init__(self, c, nof_joints, checkpoint_path, model_name="HRNet", resolution=(384, 288), interpolation=None,
+                 multiperson=True, return_heatmaps=False, return_bounding_boxes=False, max_batch_size=32,
+                 yolo_version="v3", yolo_model_def=None, yolo_class_path=None, yolo_weights_path=None, device=None,
+                 enable_tensorrt=False, *, detector=None, dtype="fp32"):
+        self.c, self.nof_joints, self.checkpoint_path = c, nof_joints, checkpoint_path
+        self.model_name, self.resolution, self.interpolation = model_name, tuple(resolution), interpolation
+        self.multiperson, self.return_heatmaps = multiperson, return_heatmaps
+        self.return_bounding_boxes, self.max_batch_size = return_bounding_boxes, max_batch_size
+        if model_name not in ("HRNet", "hrnet", "PoseResNet", "poseresnet", "ResNet", "resnet"):
+            raise ValueError("Wrong model name.")                                   # SimpleHRNet.py:114
+        if enable_tensorrt:
+            raise ValueError("TensorRT is an NVIDIA engine; this class IS the native engine on MI355X")
+        if device is None:
+            device = torch.device("cuda:0")
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise ValueError("the MI355X engine has no CPU path (device=%s)" % device)
+        self.device = torch.device("cuda", device.index or 0)
+        if multiperson and detector is None:
+            raise ValueError("multiperson=True needs detector= (the reference's YOLO wrappers are un-vendored third-party code)")
+        self.detector = detector
+        self.model = NativeHRNet(c, nof_joints, self.resolution, dtype, max_batch=max_batch_size, device=self.device,
+                                 model_name=model_name)
+        if isinstance(checkpoint_path, dict):
+            self.model.load_state_dict(checkpoint_path)
+        else:
+            self.model.load_checkpoint(checkpoint_path)                              # torch.load, raw or {'model': ...}
+
+    # ------------------------------------------------------------------------------------------ SimpleHRNet.py:174-210
+    def predict(self, image):
+        if len(image.shape) == 3:
+            return self._predict_single(image)
+        elif len(image.shape) == 4:
+            return self._predict_batch(image)
+        raise ValueError("Wrong image format.")
+
+    def _result(self, heatmaps, boxes, pts):                                       # :333-343 / :486-496
+        res = []
+        if self.return_heatmaps:
+            res.append(heatmaps)
+        if self.return_bounding_boxes:
+            res.append(boxes)
+        res.append(pts)
+        return res if len(res) > 1 else res[0]
+
+    def _normalise(self, images_bgr: np.ndarray) -> torch.Tensor:
+        """single-person transform for frames that already have the model resolution: BGR -> RGB, ToTensor, Normalize"""
+        if tuple(images_bgr.shape[-3:-1]) != self.resolution:
+            raise NotImplementedError("multiperson=False on frames of another size needs cv2.resize(INTER_CUBIC) "
+                                      "(SimpleHRNet.py:213-218), which is not reproduced here")
+        x = torch.from_numpy(np.ascontiguousarray(images_bgr[..., ::-1])).to(self.device)
+        # tensor divisors: torch turns a division by a python scalar into a multiplication by its reciprocal on the GPU,
+        # which is not the float32 division ToTensor performs
+        x = x.reshape((-1,) + x.shape[-3:]).permute(0, 3, 1, 2).to(torch.float32)
+        x = x / torch.full((1, 1, 1, 1), 255.0, dtype=torch.float32, device=self.device)
+        mean = torch.tensor(_MEAN, dtype=torch.float32, device=self.device).view(1, 3, 1, 1)
+        std = torch.tensor(_STD, dtype=torch.float32, device=self.device).view(1, 3, 1, 1)
+        return ((x - mean) / std).contiguous()
+
+    def _hm_shape(self, n):
+        return (n, self.nof_joints, self.resolution[0] // 4, self.resolution[1] // 4)
+
+    # ------------------------------------------------------------------------------------------ SimpleHRNet.py:212-343
+    def _predict_single(self, image):
+        if not self.multiperson:
+            images = self._normalise(image)
+            boxes = np.asarray([[0, 0, image.shape[1], image.shape[0]]], dtype=np.float32)
+            hm, pts = self.model.predict_crops(images, boxes, return_heatmaps=True)
+            return self._result(hm.cpu().numpy(), boxes, pts.cpu().numpy())
+        detections = self.detector.predict_single(image)
+        nof_people = len(detections) if detections is not None else 0
+        if nof_people == 0:
+            return self._result(np.zeros(self._hm_shape(0), np.float32), np.empty((0, 4), np.int32),
+                                np.empty((0, 0, 3), dtype=np.float32))             # :331
+        dets = np.asarray(detections.cpu() if isinstance(detections, torch.Tensor) else detections, np.float32)[:, :4]
+        out = self.model.predict_frame(image, dets, return_heatmaps=self.return_heatmaps)
+        boxes, pts = out[0], out[1].cpu().numpy()
+        hm = out[2].cpu().numpy() if self.return_heatmaps else None
+        return self._result(hm, boxes, pts)
+
+    # ------------------------------------------------------------------------------------------ SimpleHRNet.py:345-496
+    def _predict_batch(self, images):
+        if not self.multiperson:
+            x = self._normalise(images)
+            boxes = np.repeat(np.asarray([[0, 0, images.shape[2], images.shape[1]]], dtype=np.float32), len(images), axis=0)
+            hm, pts = self.model.predict_crops(x, boxes, return_heatmaps=True)
+            return self._result(hm.cpu().numpy(), boxes, np.expand_dims(pts.cpu().numpy(), axis=1))   # :475
+        image_detections = self.detector.predict(images)
+        crops, boxes = [], []
+        counts = []
+        for d, detections in enumerate(image_detections):
+            n = len(detections) if detections is not None else 0
+            counts.append(n if detections is not None else None)
+            if n:
+                dets = np.asarray(detections.cpu() if isinstance(detections, torch.Tensor) else detections, np.float32)[:, :4]
+                im, bx, _ = self.model.preprocess_frame(images[d], dets, "clamp")   # :383-412
+                crops.append(im), boxes.append(bx)
+        if not crops:                                                                # :477-484
+            pts = [np.zeros((0, self.nof_joints, 3), dtype=np.float32) for _ in image_detections]
+            return self._result(np.zeros(self._hm_shape(0), np.float32), np.asarray([], dtype=np.int32), pts)
+        boxes = np.concatenate(boxes, 0)
+        out = self.model.predict_crops(torch.cat(crops, 0), boxes, return_heatmaps=self.return_heatmaps)
+        hm, pts = (out[0].cpu().numpy(), out[1].cpu().numpy()) if self.return_heatmaps else (None, out.cpu().numpy())
+        pts_b, hm_b, boxes_b, index = [], [], [], 0                                  # :445-472: re-add the batch axis
+        for n in counts:
+            if n is not None:
+                pts_b.append(pts[index:index + n])
+                if hm is not None:
+                    hm_b.append(hm[index:index + n])
+                boxes_b.append(boxes[index:index + n])
+                index += n
+            else:
+                pts_b.append(np.zeros((0, self.nof_joints, 3), dtype=np.float32))
+                hm_b.append(np.zeros(self._hm_shape(0), dtype=np.float32))
+                boxes_b.append(np.zeros((0, 4), dtype=np.float32))
+        return self._result(hm_b, boxes_b, pts_b)
