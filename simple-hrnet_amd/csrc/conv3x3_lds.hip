@@ -453,12 +453,350 @@ __device__ __forceinline__ void conv3_run(const Conv3Problem &p, const int nt, c
         t_epi += tF - tE;
 #endif
     }
-#ifdef HRN_C3_TIMING
+#if defined(HRN_C3_TIMING) && !defined(HRN_C3_TIMING_FUSED_ONLY)
     if (lane == 0 && g_c3_timing) {
         C3_T(t_end);
         long long *o = g_c3_timing + ((size_t)blockIdx.x * 8 + wave) * 8;
         o[0] = t_wait, o[1] = t_issue, o[2] = t_comp, o[3] = t_epi, o[4] = t_end - t_begin, o[5] = n_half, o[6] = MR,
         o[7] = S;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A whole BasicBlock of the 48-channel branch in one pass (modules.py:56-72: conv1+BN+ReLU, conv2+BN, + x, ReLU).
+// At 144-216 FLOP per HBM byte the two convolutions are bandwidth- and vector-memory-issue-bound when run one after
+// the other; fused, the intermediate never leaves the CU and the residual is already there:
+//   LDS = W1 | W2 (2 x 42 KiB, resident for the block's whole life) | XY (76 KiB)
+//   per tile of BM = 512 output pixels (flat rows [p0, p0 + 512)), halo = wp + 1:
+//     X  = input rows [p0 - 2 halo, p0 + 512 + 2 halo)                    -> XY            (LDS-DMA, 10 pieces per wave)
+//     C1 : Y = relu(W1 * X + b1), zero on pad pixels, rows [p0 - halo, p0 + 512 + halo), as bf16
+//          (its 41-42 pixel fragments are dealt 5-6 per wave; the last one is pulled back to end on the last row);
+//          the lane's residual values (X centre rows) are read into registers, then Y overwrites X in place
+//     C2 : Z = relu(W2 * Y + b2 + X) for rows [p0, p0 + 512)               -> global
+//   and the next tile's X is requested before the epilogue's stores, which it lands under.
+// Bit-identical to the two separate launches (same K order, same bf16 rounding of Y, same epilogue arithmetic).
+// The vector-memory instructions per wave and 2 x 512 convolved pixels drop from ~43 to 18, HBM traffic from five
+// tensor passes to two; the price is 1 + 2 halo / 512 = 1.29 x the MFMAs in C1 (1.145 x overall at wp = 73).
+constexpr int BBF_W = 14 * 3 * 1024;            // one packed weight image (cout tile 0, slice 0, both parts)
+constexpr int BBF_XY = 4864 * 16;               // 810 rows of 96 B, rounded up to whole 64-lane pieces
+constexpr int BBF_LDS = 2 * BBF_W + BBF_XY;     // = 160 KiB
+static_assert(BBF_LDS <= 160 * 1024, "LDS budget");
+
+template <int NF>
+__device__ __forceinline__ void bbf_conv1(const Conv3Problem &p, const int (&xoff)[14], const int bvec, const unsigned lds0,
+                                          const int row_first, const int row_last, const long q_first, const int m,
+                                          const int lane, const unsigned res_a,
+                                          __attribute__((ext_vector_type(2))) unsigned (&rpre)[4][3], long long &t_loop) {
+    constexpr int NRB = 3, NCH = 14, ROWB = 96;
+    const int li = lane & 15, g = lane >> 4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    f32x4 acc[NF][NRB];
+    {
+        float bias[4 * NRB];
+#pragma unroll
+        for (int c = 0; c < 4 * NRB; ++c) bias[c] = __int_as_float(__builtin_amdgcn_ds_bpermute((g * 4 * NRB + c) * 4, bvec));
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{bias[j * 4], bias[j * 4 + 1], bias[j * 4 + 2], bias[j * 4 + 3]};
+    }
+    s16x8 wf[2][NRB], xf[2][NF];
+    const unsigned wl_a = lds0 + lane * 16;
+    const unsigned sl_a = lds0 + 2 * BBF_W + (row_first + li) * ROWB;
+    const unsigned sl_z = lds0 + 2 * BBF_W + (row_last + li) * ROWB;   // the wave's last fragment (may be pulled back)
+#define BBF_READ1(SET, C)                                                                                         \
+    {                                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < NRB; ++j)                                                           \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[SET][j]) : "v"(wl_a), "i"(((C)*NRB + j) * 1024)); \
+        const unsigned xa = sl_a + xoff[C], xz = sl_z + xoff[C];                                                   \
+        _Pragma("unroll") for (int i = 0; i < NF - 1; ++i)                                                        \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[SET][i]) : "v"(xa), "i"(i * 16 * ROWB));       \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(xf[SET][NF - 1]) : "v"(xz));                                     \
+    }
+    BBF_READ1(0, 0)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int cur = c & 1, nxt = cur ^ 1;
+        if (c + 1 < NCH) {
+            BBF_READ1(nxt, c + 1)
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(NRB + NF) : "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < NRB; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cur][j]),
+                                                                    __builtin_bit_cast(bf16x8, xf[cur][i]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef BBF_READ1
+#ifdef HRN_C3_TIMING
+    t_loop = __builtin_amdgcn_s_memtime();
+#endif
+    // the residual of this lane's conv2 pixels = X centre rows, fetched before Y overwrites them
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rpre[i][v]) : "v"(res_a), "i"(i * 16 * ROWB + v * 8));
+    // ReLU, zero on pad pixels and outside [0, m), bf16: the values the separate conv1 launch would have stored
+    unsigned pk[NF][2 * NRB];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int yr = (i == NF - 1 ? row_last : row_first + i * 16) + li;
+        const long q = q_first + yr;
+        const unsigned uq = (unsigned)q;
+        const int n_img = (int)(((unsigned long long)uq * p.magic_hpwp) >> p.shift_hpwp);
+        const int rem = (int)uq - n_img * p.hpwp;
+        const int ho = (int)(((unsigned long long)(unsigned)rem * p.magic_wp) >> p.shift_wp);
+        const int wo = rem - ho * p.wp;
+        const bool ok = q >= 0 && q < m && ho < p.h && wo < p.wd;
+#pragma unroll
+        for (int j = 0; j < NRB; ++j) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            const bf16x2 lo = {(__bf16)relu1(acc[i][j][0]), (__bf16)relu1(acc[i][j][1])};
+            const bf16x2 hi = {(__bf16)relu1(acc[i][j][2]), (__bf16)relu1(acc[i][j][3])};
+            pk[i][2 * j] = ok ? __builtin_bit_cast(unsigned, lo) : 0u;
+            pk[i][2 * j + 1] = ok ? __builtin_bit_cast(unsigned, hi) : 0u;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the residual reads
+    __builtin_amdgcn_s_barrier();                        // every wave is done reading X
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int yr = (i == NF - 1 ? row_last : row_first + i * 16) + li;
+        const unsigned ya = lds0 + 2 * BBF_W + yr * ROWB + g * 24;
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ya), "v"(u32x2{pk[i][2 * v], pk[i][2 * v + 1]}), "i"(v * 8) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // Y is complete
+}
+
+__device__ __forceinline__ void bbf_run(const Conv3Problem &p, const int mt0, const int tiles_this_block, const int nb, char *smem) {
+    constexpr int KS = 48, NRB = 3, ROWB = 96, NCH = 14, BM = 512, MR = 4, NT = 512;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int m = nb * p.hpwp;
+    const int mtiles = (m + BM - 1) / BM;
+    int ntile = mtiles - mt0;
+    if (ntile > tiles_this_block) ntile = tiles_this_block;
+    if (ntile <= 0) return;
+    const int halo = p.wp + 1;
+    const int xrows = BM + 4 * halo, yrows = BM + 2 * halo;
+    const int xunits = xrows * 6;
+    // conv1's pixel fragments: nfr of them, dealt to the waves base or base + 1 each, contiguous
+    const int nfr = (yrows + 15) >> 4, base = nfr >> 3, extra = nfr & 7;
+    const int cnt = base + (wave < extra ? 1 : 0);
+    const int f0 = wave * base + (wave < extra ? wave : extra);
+    const int row_first = f0 * 16;
+    int row_last = (f0 + cnt - 1) * 16;
+    if (row_last > yrows - 16) row_last = yrows - 16;   // the last fragment ends on the last row (recomputes a few)
+    const gcu16 in = (gcu16)p.in;
+    const gu16 out = (gu16)p.out;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    char *const xy = smem + 2 * BBF_W;
+
+    int xoff[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        int k0 = 32 * c + 8 * g;
+        if (k0 >= 9 * KS) k0 = 0;
+        const int tap = k0 / KS, ci = k0 - tap * KS;
+        const int dh = tap / 3, dw = tap - 3 * dh;
+        xoff[c] = (dh * p.wp + dw) * ROWB + (ci >> 3) * 16;
+    }
+    const int ch0 = g * 4 * NRB;
+    // the 48 biases of each convolution sit one per lane; a lane picks its twelve with ds_bpermute when it needs them
+    // (24 registers less across the tile loop -- the next tile's X is parked in registers during conv2)
+    const int bl = lane < KS ? lane : 0;
+    const int bvec1 = __float_as_int(((const GLOBAL_AS float *)p.bias)[bl]);
+    const int bvec2 = __float_as_int(((const GLOBAL_AS float *)p.bias2)[bl]);
+    // X of tile tt -> XY.  Rows outside the tensor's guard bands are clamped to a mapped row: whatever they hold only
+    // reaches Y rows outside [0, m), which are zeroed.
+    auto load_x = [&](int tt) {
+        const long row0 = (long)(mt0 + tt) * BM - 2 * halo;
+        const long lo = -(long)halo, hi = (long)m + halo + 511;
+#pragma unroll
+        for (int k = 0; k < BBF_XY / 16 / NT + 1; ++k) {
+            if (k * NT + wave * 64 < xunits) {
+                int u = k * NT + tid;
+                asm volatile("" : "+v"(u));  // recompute the address per tile: hoisted, the ten 64-bit offsets spill
+                if (u >= xunits) u = xunits - 1;
+                const int r = (int)(((unsigned)u * 43691u) >> 18);   // u / 6 for u < 2^16
+                const int q8 = u - r * 6;
+                long gr = row0 + r;
+                gr = gr < lo ? lo : (gr > hi ? hi : gr);
+                glds16((const GLOBAL_AS char *)(in + gr * KS + q8 * 8), xy + (k * NT + wave * 64) * 16);
+            }
+        }
+    };
+    // The same X, for the tiles after the first, through registers: requested when conv2 starts and written to XY
+    // once conv2 has finished with Y -- conv2's compute time to land, nothing exposed but ten ds_write.
+    // Pieces 0..7 (units < 4096) go through registers; pieces 8 and 9 land beyond Y's last row (660 rows = 3960 units
+    // at most), which nothing reads during conv2: those go straight to their place by LDS-DMA.
+    constexpr int NXP = BBF_XY / 16 / NT + 1, NXR = 8;
+    u32x4 xpre[NXR];
+    auto x_src = [&](int tt, int k) {
+        const long row0 = (long)(mt0 + tt) * BM - 2 * halo;
+        const long lo = -(long)halo, hi = (long)m + halo + 511;
+        int u = k * NT + tid;
+        asm volatile("" : "+v"(u));
+        if (u >= xunits) u = xunits - 1;
+        const int r = (int)(((unsigned)u * 43691u) >> 18);
+        const int q8 = u - r * 6;
+        long gr = row0 + r;
+        gr = gr < lo ? lo : (gr > hi ? hi : gr);
+        return in + gr * KS + q8 * 8;
+    };
+    auto fetch_x = [&](int tt) {
+#pragma unroll
+        for (int k = 0; k < NXR; ++k) {   // (unconditional: a piece past the end re-reads the last unit and is not written)
+            const gcu16 src = x_src(tt, k);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xpre[k]) : "v"(src));
+        }
+#pragma unroll
+        for (int k = NXR; k < NXP; ++k)
+            if (k * NT + wave * 64 < xunits) glds16((const GLOBAL_AS char *)x_src(tt, k), xy + (k * NT + wave * 64) * 16);
+    };
+    auto store_x = [&]() {
+        const unsigned a0 = lds0 + 2 * BBF_W + tid * 16;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // registers and LDS-DMA alike
+#pragma unroll
+        for (int k = 0; k < NXR; ++k)
+            if (k * NT + wave * 64 < xunits)
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a0), "v"(xpre[k]), "i"(k * NT * 16) : "memory");
+    };
+    {   // both weight images, once per block
+        const GLOBAL_AS char *w1 = (const GLOBAL_AS char *)p.w, *w2 = (const GLOBAL_AS char *)p.w2;
+#pragma unroll
+        for (int k = 0; k < (BBF_W / 16 + NT - 1) / NT; ++k) {
+            const int u0 = k * NT + wave * 64;
+            if (u0 < BBF_W / 16) {
+                glds16(w1 + (size_t)(u0 + lane) * 16, smem + u0 * 16);
+                glds16(w2 + (size_t)(u0 + lane) * 16, smem + BBF_W + u0 * 16);
+            }
+        }
+        load_x(0);
+    }
+#ifdef HRN_C3_TIMING
+    long long t_w = 0, t_c1 = 0, t_c1p = 0, t_c2 = 0, t_post = 0, t_epi = 0;
+    C3_T(t_begin);
+#endif
+    for (int tt = 0; tt < ntile; ++tt) {
+        C3_T(tA);
+        if (tt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the block's LDS-DMA: weights and the first X
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // later tiles: this wave's share of X is written
+        __builtin_amdgcn_s_barrier();  // X (and the weights) are in LDS for every wave
+        const long p0 = (long)(mt0 + tt) * BM;
+        C3_T(tB);
+        long long tC = 0;
+        u32x2 rpre[MR][3];
+        const unsigned res_a = lds0 + 2 * BBF_W + (wave * 16 * MR + li + 2 * halo) * ROWB + g * 24;
+        if (cnt == 6)
+            bbf_conv1<6>(p, xoff, bvec1, lds0, row_first, row_last, p0 - halo, m, lane, res_a, rpre, tC);
+        else if (cnt == 5)
+            bbf_conv1<5>(p, xoff, bvec1, lds0, row_first, row_last, p0 - halo, m, lane, res_a, rpre, tC);
+        else
+            bbf_conv1<4>(p, xoff, bvec1, lds0, row_first, row_last, p0 - halo, m, lane, res_a, rpre, tC);
+        C3_T(tD);
+        // ---- conv2 over Y: the chunk loop of conv3_run with both weight parts resident
+        if (tt + 1 < ntile) fetch_x(tt + 1);   // the next tile's X lands in registers meanwhile
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[MR][NRB];
+        {
+            float bias2[4 * NRB];
+#pragma unroll
+            for (int c = 0; c < 4 * NRB; ++c) bias2[c] = __int_as_float(__builtin_amdgcn_ds_bpermute((ch0 + c) * 4, bvec2));
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{bias2[j * 4], bias2[j * 4 + 1], bias2[j * 4 + 2], bias2[j * 4 + 3]};
+        }
+        {
+            s16x8 wf[2][NRB], xf[2][MR];
+            const unsigned wl_a = lds0 + BBF_W + lane * 16;
+            const unsigned sl_a = lds0 + 2 * BBF_W + (wave * 16 * MR + li) * ROWB;
+#define BBF_READ2(SET, C)                                                                                         \
+    {                                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < NRB; ++j)                                                           \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[SET][j]) : "v"(wl_a), "i"(((C)*NRB + j) * 1024)); \
+        const unsigned xa = sl_a + xoff[C];                                                                        \
+        _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                            \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[SET][i]) : "v"(xa), "i"(i * 16 * ROWB));       \
+    }
+            BBF_READ2(0, 0)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int cur = c & 1, nxt = cur ^ 1;
+                if (c + 1 < NCH) {
+                    BBF_READ2(nxt, c + 1)
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(NRB + MR) : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NRB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[cur][j]),
+                                                                            __builtin_bit_cast(bf16x8, xf[cur][i]), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef BBF_READ2
+        }
+        C3_T(tE);
+        __builtin_amdgcn_s_barrier();  // every wave is done reading Y: XY may be refilled
+        if (tt + 1 < ntile) store_x();
+        __builtin_amdgcn_sched_barrier(0);
+        C3_T(tF);
+        // ---- epilogue of conv2 (as in conv3_run): + residual, ReLU, zero on pad pixels, 24 contiguous bytes per lane
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            const int q = (int)p0 + wave * 16 * MR + i * 16 + li;
+            const int n_img = (int)(((unsigned long long)(unsigned)q * p.magic_hpwp) >> p.shift_hpwp);
+            const int rem = q - n_img * p.hpwp;
+            const int ho = (int)(((unsigned long long)(unsigned)rem * p.magic_wp) >> p.shift_wp);
+            const int wo = rem - ho * p.wp;
+            const bool ok = (q < m) && (ho < p.h) && (wo < p.wd);
+            const size_t o = (size_t)q * KS + ch0;
+            unsigned pk[2 * NRB];
+#pragma unroll
+            for (int j = 0; j < NRB; ++j) {
+                const unsigned r01 = rpre[i][j][0], r23 = rpre[i][j][1];
+                float v0 = acc[i][j][0] + __uint_as_float(r01 << 16);
+                float v1 = acc[i][j][1] + __uint_as_float(r01 & 0xffff0000u);
+                float v2 = acc[i][j][2] + __uint_as_float(r23 << 16);
+                float v3 = acc[i][j][3] + __uint_as_float(r23 & 0xffff0000u);
+                if (p.relu) v0 = relu1(v0), v1 = relu1(v1), v2 = relu1(v2), v3 = relu1(v3);
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                const bf16x2 lo = {(__bf16)v0, (__bf16)v1}, hi = {(__bf16)v2, (__bf16)v3};
+                pk[2 * j] = ok ? __builtin_bit_cast(unsigned, lo) : 0u;
+                pk[2 * j + 1] = ok ? __builtin_bit_cast(unsigned, hi) : 0u;
+            }
+            *(GLOBAL_AS u32x4 *)(out + o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            *(GLOBAL_AS u32x2 *)(out + o + 8) = u32x2{pk[4], pk[5]};
+        }
+#ifdef HRN_C3_TIMING
+        C3_T(tG);
+        t_w += tB - tA, t_c1 += tC - tB, t_c1p += tD - tC, t_c2 += tE - tD, t_post += tF - tE, t_epi += tG - tF;
+#endif
+    }
+#ifdef HRN_C3_TIMING
+    if (lane == 0 && g_c3_timing) {
+        C3_T(t_end);
+        long long *o = g_c3_timing + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = t_w, o[1] = t_c1, o[2] = t_c1p, o[3] = t_c2, o[4] = t_end - t_begin, o[5] = ntile, o[6] = 100 + cnt,
+        o[7] = t_post | (t_epi << 32);
     }
 #endif
 }
@@ -474,7 +812,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem 
     const int nt = (bm.x >> 8) & 0xff, tiles = bm.x >> 16;
     // y = first M tile | small << 30.  small: 128-pixel tiles (MR = 1) -- the host asks for them when even one tile
     // per block would leave CUs idle (a few crops): four times the blocks, a quarter of the MFMAs on a block's serial path
-    const int mt0 = bm.y & 0x3fffffff;
+    const int mt0 = bm.y & 0x1fffffff;
+    if constexpr (KS == 48 && NRB == 3) {
+        if (bm.y & (1 << 29)) {  // a fused BasicBlock (bbf_run): 512-pixel tiles, both convolutions
+            bbf_run(p, mt0, tiles, nb, smem);
+            return;
+        }
+    }
     if (bm.y >> 30) {
         conv3_run<CFG, 1>(p, nt, mt0, tiles, nb, smem);
     } else if constexpr (NRB == 4) {  // 64 accumulator + 64 fragment registers at MR = 4 would spill: 384-pixel tiles only
@@ -506,16 +850,20 @@ extern "C" int hrn_debug_c3_timing(long long *host_out, int max_blocks) {
 template <int KS, int NRB>
 static hipError_t launch_c3(const Conv3Problem *probs_dev, const int2 *blockmap_dev, int nblocks, int nb, hipStream_t s) {
     using CFG = C3Cfg<KS, NRB>;
+    // the <48, 3> launches may carry fused BasicBlocks (bbf_run), which lay LDS out differently and use all of it
+    constexpr int LDS = (KS == 48 && NRB == 3 && BBF_LDS > CFG::LDS) ? BBF_LDS : CFG::LDS;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)conv3x3_lds_kernel<KS, NRB>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_lds_kernel<KS, NRB>), dim3(nblocks), dim3(512), CFG::LDS, s, probs_dev, blockmap_dev, nb);
+    hipLaunchKernelGGL((conv3x3_lds_kernel<KS, NRB>), dim3(nblocks), dim3(512), LDS, s, probs_dev, blockmap_dev, nb);
     return hipGetLastError();
 }
+
+int conv3x3_lds_bbf_ok(int wp) { return (512 + 4 * (wp + 1)) * 6 <= BBF_XY / 16; }
 
 // pixels per M tile for a (KS, wp) pair: 512, or 384 when two 512-row slabs (+ halo) would not fit in LDS; 0 = unsupported
 int conv3x3_lds_bm(int ks, int nrb, int wp) {

@@ -47,6 +47,8 @@ struct ConvOp {
     int algo = 0;          // 0 = generic kernel (kernels.hip), 1 = pipelined LDS-staged 3x3 stride 1 (conv3x3_lds.hip)
     int up = 0;            // 1 + 2a + b: phase (a, b) of a ConvTranspose2d(4, s2, p1) as a 3x3 conv on the input grid
     int ks = 0, slices = 0, ntiles = 0, nch = 0;
+    int fuse_with = -1;    // conv1 of a BasicBlock that also computes this conv2 (conv3x3_lds.hip: bbf_run)
+    bool fused_away = false;  // conv2 of such a block: no launch of its own
     int64_t w_off = 0, w_bytes = 0, b_off = 0;
     double flops = 0;
 };
@@ -143,6 +145,9 @@ struct hrn_ctx {
     bool small_tiles = getenv("HRN_SMALL_TILES") ? atoi(getenv("HRN_SMALL_TILES")) != 0 : true;
     int small_below = getenv("HRN_SMALL_BELOW") ? atoi(getenv("HRN_SMALL_BELOW")) : 384;
     bool disable_chain_ds = getenv("HRN_DISABLE_CHAIN_DS") != nullptr;
+    // fused BasicBlocks on the 48-channel branch (conv3x3_lds.hip: bbf_run): bit-identical, 2.5x less HBM traffic on that
+    // branch, +2.6 % on the whole pass at 256 crops; HRN_BBF=0 goes back to two launches per block
+    bool disable_bbf = getenv("HRN_BBF") && atoi(getenv("HRN_BBF")) == 0;
     // 1: convolutions that read the same tensor share one cout-tile width so that they can share a launch (and L2)
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
@@ -326,7 +331,16 @@ struct hrn_ctx {
                 snprintf(buf, sizeof buf, "%s.branches.%d.%d", name.c_str(), b, k);
                 const std::string p = buf;
                 const int t2 = add_conv(p + ".conv2", p + ".bn2", t1[b], c << b, 3, 1, 1, xs[b], false);
-                g2.push_back((int)convs.size() - 1);
+                const int i2 = (int)convs.size() - 1, i1 = g1[b];
+                // a 48 -> 48 -> 48 block in bf16: both convolutions in one pass over the tile, Y stays in LDS
+                const ConvOp &a1 = convs[i1], &a2 = convs[i2];
+                if (!disable_bbf && dtype == 1 && a1.algo == 1 && a2.algo == 1 && a1.ks == 48 && a1.nr == 3 && a1.slices == 1 &&
+                    a1.ntiles == 1 && a2.slices == 1 && a2.ntiles == 1 && conv3x3_lds_bbf_ok(tensors[t2].wp)) {
+                    convs[i1].fuse_with = i2;
+                    convs[i2].fused_away = true;
+                } else {
+                    g2.push_back(i2);
+                }
                 release(t1[b]);
                 release(xs[b]);
                 xs[b] = t2;
@@ -599,18 +613,26 @@ struct hrn_ctx {
         for (int ci : g.conv_idx) {
             const ConvOp &cv = convs[ci];
             const Tensor &to = tensors[cv.out_t];
-            const int bmn = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+            const int bmn = cv.fuse_with >= 0 ? 512 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
             one_per_block += (long)((nb * to.hpwp + bmn - 1) / bmn) * cv.ntiles;
         }
         const bool small = small_tiles && one_per_block < small_below;
+        // a fused BasicBlock walks 512-pixel tiles through both convolutions (no small-tile mode): about three
+        // ordinary 384-pixel tiles' worth of work each
+        auto tile_px = [&](const ConvOp &cv, const Tensor &to) {
+            return cv.fuse_with >= 0 ? 512 : small ? 128 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+        };
+        auto tiles_per_block = [&](const ConvOp &cv, int div) {
+            return std::max(1, conv3_tiles_per_block(cv) / (cv.fuse_with >= 0 ? 3 : 1) / div);
+        };
         auto count_blocks = [&](int div) {
             long total = 0;
             for (int ci : g.conv_idx) {
                 const ConvOp &cv = convs[ci];
                 const Tensor &to = tensors[cv.out_t];
-                const int bm = small ? 128 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+                const int bm = tile_px(cv, to);
                 const int mtiles = (nb * to.hpwp + bm - 1) / bm;
-                const int tpb = std::max(1, conv3_tiles_per_block(cv) / div);
+                const int tpb = tiles_per_block(cv, div);
                 total += (long)((mtiles + tpb - 1) / tpb) * cv.ntiles;
             }
             return total;
@@ -622,11 +644,12 @@ struct hrn_ctx {
         for (size_t k = 0; k < g.conv_idx.size(); ++k) {
             const ConvOp &cv = convs[g.conv_idx[k]];
             const Tensor &to = tensors[cv.out_t];
-            const int bm = small ? 128 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+            const int bm = tile_px(cv, to);
+            const bool fused = cv.fuse_with >= 0;
             const int mtiles = (nb * to.hpwp + bm - 1) / bm;
             // Blocks come in two lengths: long ones (fewer pipeline prologues -- a block's first loads have nothing to
             // hide behind) over the first `long_share` of the M tiles, short ones over the rest to fill the tail.
-            const int tpb_short = std::max(1, conv3_tiles_per_block(cv) / div);
+            const int tpb_short = tiles_per_block(cv, div);
             const int tpb_long = tpb_short * lf;
             const int long_tiles = ((int)(mtiles * long_share) / (8 * tpb_long)) * (8 * tpb_long);  // whole XCD rounds
             for (int phase = 0; phase < 2; ++phase) {
@@ -650,12 +673,12 @@ struct hrn_ctx {
                             if (tiles > tpb) tiles = tpb;
                             double key = (i + 0.5) / total;  // proportional interleave of the problems
                             if (block_order == 1)            // longest-processing-time first (estimated block cost)
-                                key = -(double)tiles * (cv.slices * 2.0 * (bm == 512 ? 4300.0 : 3500.0) + (bm == 512 ? 5000.0 : 3000.0)) + 1e-3 * key;
+                                key = -(double)tiles * (fused ? 28000.0 : cv.slices * 2.0 * (bm == 512 ? 4300.0 : 3500.0) + (bm == 512 ? 5000.0 : 3000.0)) + 1e-3 * key;
                             int mt0 = first + mg * tpb;
                             // every other launch walks the tensors backwards: a launch starts on what its producer
                             // wrote last, i.e. on the part most likely still in the Infinity Cache
                             if (reverse) mt0 = mtiles - mt0 - tiles;
-                            ents.push_back({key, int2{(int)k | (nt << 8) | (tiles << 16), mt0 | (small ? 1 << 30 : 0)}});
+                            ents.push_back({key, int2{(int)k | (nt << 8) | (tiles << 16), mt0 | (fused ? 1 << 29 : small ? 1 << 30 : 0)}});
                         }
             }
         }
@@ -760,6 +783,12 @@ struct hrn_ctx {
                 q.res = cv.res_t >= 0 ? row0(cv.res_t) : nullptr;
                 q.cin = cv.cin, q.cout = cv.cout, q.h = to.h, q.wd = to.w, q.wp = to.wp, q.hpwp = to.hpwp;
                 q.relu = cv.relu, q.slices = cv.slices, q.ntiles = cv.ntiles;
+                q.w2 = nullptr, q.bias2 = nullptr;
+                if (cv.fuse_with >= 0) {  // the whole BasicBlock: in = x (also the residual), out = the block's output
+                    const ConvOp &c2 = convs[cv.fuse_with];
+                    q.out = row0(c2.out_t), q.relu = c2.relu;
+                    q.w2 = blob + c2.w_off, q.bias2 = (const float *)(blob + c2.b_off);
+                }
                 q.tiles_per_block = conv3_tiles_per_block(cv);
                 q.bm = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
                 fast_div(to.hpwp, &q.magic_hpwp, &q.shift_hpwp);
@@ -1469,7 +1498,7 @@ int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out) {
     out->has_residual = cv.res_t >= 0;
     out->in_h = h->tensors[cv.in_t].h, out->in_w = h->tensors[cv.in_t].w;
     out->out_h = h->tensors[cv.out_t].h, out->out_w = h->tensors[cv.out_t].w;
-    out->kpad = cv.kpad, out->nr = cv.nr, out->algo = cv.algo, out->ks = cv.ks;
+    out->kpad = cv.kpad, out->nr = cv.nr, out->algo = cv.fuse_with >= 0 || cv.fused_away ? 2 : cv.algo, out->ks = cv.ks;
     out->w_offset = cv.w_off, out->w_bytes = cv.w_bytes, out->b_offset = cv.b_off;
     out->flops = cv.flops;
     return 0;
@@ -1510,10 +1539,13 @@ int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms
                 if (conv_ms && op.idx < conv_ms_len) conv_ms[op.idx] = ms;
             } else if (op.kind == OP_CONV3_GROUP) {  // one launch, several convs: split by FLOPs
                 const Conv3Group &g = h->groups[op.idx];
-                double tot = 0;
-                for (int ci : g.conv_idx) tot += h->convs[ci].flops;
-                for (int ci : g.conv_idx)
+                double tot = 0;  // (a fused BasicBlock's launch carries its conv2 as well)
+                for (int ci : g.conv_idx) tot += h->convs[ci].flops + (h->convs[ci].fuse_with >= 0 ? h->convs[h->convs[ci].fuse_with].flops : 0.0);
+                for (int ci : g.conv_idx) {
                     if (conv_ms && ci < conv_ms_len) conv_ms[ci] = (float)(ms * h->convs[ci].flops / tot);
+                    const int c2 = h->convs[ci].fuse_with;
+                    if (conv_ms && c2 >= 0 && c2 < conv_ms_len) conv_ms[c2] = (float)(ms * h->convs[c2].flops / tot);
+                }
             } else if (op.kind == OP_CONV_GROUP) {  // likewise; these are latency / bandwidth bound: split by block count
                 const DirectGroup &g = h->dgroups[op.idx];
                 double tot = 0;

@@ -50,7 +50,12 @@ struct Conv3Problem {
     // x / d == (x * magic) >> shift for x < 2^27, magic = floor(2^shift / d) + 1, shift = 30 + ceil(log2 d)
     unsigned magic_hpwp, magic_wp;
     int shift_hpwp, shift_wp;
+    // fused BasicBlock (conv3x3_lds.hip: bbf_run): this problem is conv1, w2 / bias2 are conv2's, `out` is the block's
+    // output and `in` doubles as the residual
+    const void *w2;
+    const float *bias2;
 };
+int conv3x3_lds_bbf_ok(int wp);  // the fused BasicBlock kernel fits this row pitch
 int conv3x3_lds_bm(int ks, int nrb, int wp);
 
 // layer1: conv3 (+shortcut, ReLU) of one Bottleneck and conv1 (+ReLU) of the next in one pass (bottleneck_chain.hip)

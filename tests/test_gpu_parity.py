@@ -251,7 +251,7 @@ def test_scheduling_variants_are_bit_identical(pkg, dtype, monkeypatch):
     boxes = pkg.synth_boxes(n, seed=22)
 
     def run(env):
-        for k in ("HRN_DISABLE_DGROUP", "HRN_DISABLE_CHAIN", "HRN_DISABLE_CHAIN_DS", "HRN_SMALL_TILES", "HRN_DGROUP_NR", "HRN_ALTERNATE", "HRN_DISABLE_GROUP", "HRN_BLOCK_ORDER",
+        for k in ("HRN_DISABLE_DGROUP", "HRN_DISABLE_CHAIN", "HRN_DISABLE_CHAIN_DS", "HRN_BBF", "HRN_SMALL_TILES", "HRN_DGROUP_NR", "HRN_ALTERNATE", "HRN_DISABLE_GROUP", "HRN_BLOCK_ORDER",
                   "HRN_LONG_FACTOR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -263,11 +263,32 @@ def test_scheduling_variants_are_bit_identical(pkg, dtype, monkeypatch):
         return out
 
     base = run({})
-    for env in ({"HRN_DISABLE_DGROUP": "1"}, {"HRN_DISABLE_CHAIN": "1"}, {"HRN_DISABLE_CHAIN_DS": "1"}, {"HRN_SMALL_TILES": "0"}, {"HRN_DGROUP_NR": "0"}, {"HRN_ALTERNATE": "0"}, {"HRN_DISABLE_GROUP": "1"},
+    for env in ({"HRN_DISABLE_DGROUP": "1"}, {"HRN_DISABLE_CHAIN": "1"}, {"HRN_DISABLE_CHAIN_DS": "1"}, {"HRN_BBF": "0"}, {"HRN_SMALL_TILES": "0"}, {"HRN_DGROUP_NR": "0"}, {"HRN_ALTERNATE": "0"}, {"HRN_DISABLE_GROUP": "1"},
                 {"HRN_BLOCK_ORDER": "0", "HRN_LONG_FACTOR": "1"}):
         hm, pts = run(env)
         np.testing.assert_array_equal(hm, base[0], err_msg=str(env))
         np.testing.assert_array_equal(pts, base[1], err_msg=str(env))
+
+
+@pytest.mark.parametrize("h,w,n,mb", [(384, 288, 3, 4), (384, 288, 7, 3), (256, 192, 5, 8), (64, 64, 9, 16)])
+def test_fused_basicblock_is_bit_identical(pkg, monkeypatch, h, w, n, mb):
+    """The fused BasicBlock pass of the 48-channel branch (conv3x3_lds.hip: bbf_run) against the two separate launches:
+    same bits, at the row pitches that deal conv1's fragments 6/5, 5/4 and 4 per wave, with ragged last micro-batches."""
+    crops = torch.from_numpy(pkg.synth_crops(n, h, w, seed=41)).cuda()
+    boxes = pkg.synth_boxes(n, seed=42)
+    outs = []
+    for on in (True, False):
+        monkeypatch.delenv("HRN_BBF", raising=False)
+        if not on:
+            monkeypatch.setenv("HRN_BBF", "0")
+        net = _engine(pkg, 48, h, w, "bf16", max_batch=mb, seed=3)
+        hm, pts = net.predict_crops(crops, boxes, return_heatmaps=True)
+        outs.append((hm.cpu().numpy(), pts.cpu().numpy(), sum(i.algo == 2 for i in net.conv_infos())))
+        net.close()
+    assert np.isfinite(outs[0][0]).all()
+    assert outs[0][2] == 64 and outs[1][2] == 0   # all 32 BasicBlocks of the 48-channel branch went through the fused pass
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
 def test_bf16_head_mfma_vs_fp32_weight_head(pkg, monkeypatch):

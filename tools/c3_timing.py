@@ -8,7 +8,8 @@ lib_mod.HIPCC_FLAGS.append("-DHRN_C3_TIMING")
 for extra in os.environ.get("C3_DEFS", "").split():
     lib_mod.HIPCC_FLAGS.append("-D" + extra)
 lib_mod.LIB_PATH = lib_mod.LIB_PATH.replace(".so", "_timing.so")
-lib_mod.build(force=True)
+if not os.environ.get("NO_BUILD"):   # NO_BUILD=1: the _timing.so was built beforehand (no GPU needed for that)
+    lib_mod.build(force=True)
 import torch
 pkg = importlib.import_module("simple-hrnet_amd")
 mb = int(os.environ.get("MB", "64"))
@@ -23,6 +24,17 @@ for _ in range(3):
     net(x)
 torch.cuda.synchronize()
 lib.hrn_debug_c3_timing(buf.ctypes.data, NB)
+fz = buf[buf[:, 0, 6] >= 100]   # fused BasicBlock blocks (bbf_run) record their own phases
+if len(fz):
+    nt = fz[:, 0, 5].astype(float)
+    print("fused BasicBlock blocks: %d, %.1f tiles/block, total/tile %.0f ticks" % (len(fz), nt.mean(), (fz[:, 0, 4] / nt).mean()))
+    for w in range(8):
+        per = lambda col: (fz[:, w, col] / nt).mean()
+        post = ((fz[:, w, 7] & 0xffffffff) / nt).mean()
+        epi = ((fz[:, w, 7] >> 32) / nt).mean()
+        print("    wave %d (%d frags): top wait %.0f  conv1 loop %.0f  conv1 tail %.0f  conv2 loop %.0f  refill %.0f  epilogue %.0f" % (
+            w, fz[0, w, 6] - 100, per(0), per(1), per(2), per(3), post, epi))
+    buf[buf[:, 0, 6] >= 100] = 0
 b = buf[buf[:, 0, 5] > 0]
 print("blocks of the last grouped launch:", len(b))
 for mr in (2, 4, 8):
