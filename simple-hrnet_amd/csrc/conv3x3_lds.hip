@@ -501,10 +501,27 @@ __device__ __forceinline__ void bbf_conv1(const Conv3Problem &p, const int (&xof
 #pragma unroll
             for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{bias[j * 4], bias[j * 4 + 1], bias[j * 4 + 2], bias[j * 4 + 3]};
     }
+    // which of this lane's NF pixels are real (not pad, inside [0, m)): worked out ahead of the loop, where the VALU
+    // work hides under the SIMD partner's MFMAs, instead of in the tail everybody waits for
+    unsigned okbits = 0;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int yr = (i == NF - 1 ? row_last : row_first + i * 16) + li;
+        const long q = q_first + yr;
+        const unsigned uq = (unsigned)q;
+        const int n_img = (int)(((unsigned long long)uq * p.magic_hpwp) >> p.shift_hpwp);
+        const int rem = (int)uq - n_img * p.hpwp;
+        const int ho = (int)(((unsigned long long)(unsigned)rem * p.magic_wp) >> p.shift_wp);
+        const int wo = rem - ho * p.wp;
+        okbits |= (q >= 0 && q < m && ho < p.h && wo < p.wd) ? 1u << i : 0u;
+    }
     s16x8 wf[2][NRB], xf[2][NF];
     const unsigned wl_a = lds0 + lane * 16;
-    const unsigned sl_a = lds0 + 2 * BBF_W + (row_first + li) * ROWB;
-    const unsigned sl_z = lds0 + 2 * BBF_W + (row_last + li) * ROWB;   // the wave's last fragment (may be pulled back)
+    unsigned sl_a = lds0 + 2 * BBF_W + (row_first + li) * ROWB;
+    unsigned sl_z = lds0 + 2 * BBF_W + (row_last + li) * ROWB;   // the wave's last fragment (may be pulled back)
+    // (opaque per call: otherwise the 28 per-chunk addresses sl + xoff[c] are hoisted out of the tile loop and held in
+    // registers across it -- the registers the next tile's X needs during conv2)
+    asm volatile("" : "+v"(sl_a), "+v"(sl_z));
 #define BBF_READ1(SET, C)                                                                                         \
     {                                                                                                             \
         _Pragma("unroll") for (int j = 0; j < NRB; ++j)                                                           \
@@ -547,14 +564,7 @@ __device__ __forceinline__ void bbf_conv1(const Conv3Problem &p, const int (&xof
     unsigned pk[NF][2 * NRB];
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
-        const int yr = (i == NF - 1 ? row_last : row_first + i * 16) + li;
-        const long q = q_first + yr;
-        const unsigned uq = (unsigned)q;
-        const int n_img = (int)(((unsigned long long)uq * p.magic_hpwp) >> p.shift_hpwp);
-        const int rem = (int)uq - n_img * p.hpwp;
-        const int ho = (int)(((unsigned long long)(unsigned)rem * p.magic_wp) >> p.shift_wp);
-        const int wo = rem - ho * p.wp;
-        const bool ok = q >= 0 && q < m && ho < p.h && wo < p.wd;
+        const bool ok = (okbits >> i) & 1u;
 #pragma unroll
         for (int j = 0; j < NRB; ++j) {
             typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -645,24 +655,25 @@ __device__ __forceinline__ void bbf_run(const Conv3Problem &p, const int mt0, co
     // at most), which nothing reads during conv2: those go straight to their place by LDS-DMA.
     constexpr int NXP = BBF_XY / 16 / NT + 1, NXR = 8;
     u32x4 xpre[NXR];
+    // unit u = k * 512 + tid of the X image is slot u % 6 of row u / 6; 512 = 85 * 6 + 2, so piece k follows from piece 0
+    const int r0u = (int)(((unsigned)tid * 43691u) >> 18), q0u = tid - r0u * 6;
     auto x_src = [&](int tt, int k) {
-        const long row0 = (long)(mt0 + tt) * BM - 2 * halo;
-        const long lo = -(long)halo, hi = (long)m + halo + 511;
-        int u = k * NT + tid;
-        asm volatile("" : "+v"(u));
-        if (u >= xunits) u = xunits - 1;
-        const int r = (int)(((unsigned)u * 43691u) >> 18);
-        const int q8 = u - r * 6;
-        long gr = row0 + r;
+        const int row0 = (mt0 + tt) * BM - 2 * halo;   // (all row numbers fit 32 bits: m < 2^27)
+        int r = r0u, q8 = q0u;
+        asm volatile("" : "+v"(r), "+v"(q8));          // derive per tile: hoisted, the ten row / slot pairs would spill
+        r += 85 * k + (2 * k) / 6, q8 += (2 * k) % 6;
+        if (q8 >= 6) q8 -= 6, ++r;
+        if (r >= xrows) r = xrows - 1, q8 = 5;          // past the end: re-read the last unit
+        int gr = row0 + r;
+        const int lo = -halo, hi = m + halo + 511;
         gr = gr < lo ? lo : (gr > hi ? hi : gr);
-        return in + gr * KS + q8 * 8;
+        return in + ((long)gr * KS + q8 * 8);
     };
     auto fetch_x = [&](int tt) {
 #pragma unroll
-        for (int k = 0; k < NXR; ++k) {   // (unconditional: a piece past the end re-reads the last unit and is not written)
-            const gcu16 src = x_src(tt, k);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xpre[k]) : "v"(src));
-        }
+        // (unconditional: a piece past the end re-reads the last unit and is not written.  Plain loads, not inline asm:
+        // should the register allocator ever spill one, the compiler waits for it first -- slower, never wrong)
+        for (int k = 0; k < NXR; ++k) xpre[k] = *(const GLOBAL_AS u32x4 *)x_src(tt, k);
 #pragma unroll
         for (int k = NXR; k < NXP; ++k)
             if (k * NT + wave * 64 < xunits) glds16((const GLOBAL_AS char *)x_src(tt, k), xy + (k * NT + wave * 64) * 16);
@@ -710,6 +721,16 @@ __device__ __forceinline__ void bbf_run(const Conv3Problem &p, const int mt0, co
         C3_T(tD);
         // ---- conv2 over Y: the chunk loop of conv3_run with both weight parts resident
         if (tt + 1 < ntile) fetch_x(tt + 1);   // the next tile's X lands in registers meanwhile
+        unsigned okbits2 = 0;                  // the epilogue's pad mask, ahead of the loop for the same reason as conv1's
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            const int q = (int)p0 + wave * 16 * MR + i * 16 + li;
+            const int n_img = (int)(((unsigned long long)(unsigned)q * p.magic_hpwp) >> p.shift_hpwp);
+            const int rem = q - n_img * p.hpwp;
+            const int ho = (int)(((unsigned long long)(unsigned)rem * p.magic_wp) >> p.shift_wp);
+            const int wo = rem - ho * p.wp;
+            okbits2 |= ((q < m) && (ho < p.h) && (wo < p.wd)) ? 1u << i : 0u;
+        }
         __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[MR][NRB];
         {
@@ -724,7 +745,8 @@ __device__ __forceinline__ void bbf_run(const Conv3Problem &p, const int mt0, co
         {
             s16x8 wf[2][NRB], xf[2][MR];
             const unsigned wl_a = lds0 + BBF_W + lane * 16;
-            const unsigned sl_a = lds0 + 2 * BBF_W + (wave * 16 * MR + li) * ROWB;
+            unsigned sl_a = lds0 + 2 * BBF_W + (wave * 16 * MR + li) * ROWB;
+            asm volatile("" : "+v"(sl_a));   // (as in conv1: keep the per-chunk addresses out of the loop-carried registers)
 #define BBF_READ2(SET, C)                                                                                         \
     {                                                                                                             \
         _Pragma("unroll") for (int j = 0; j < NRB; ++j)                                                           \
@@ -763,11 +785,7 @@ __device__ __forceinline__ void bbf_run(const Conv3Problem &p, const int mt0, co
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
             const int q = (int)p0 + wave * 16 * MR + i * 16 + li;
-            const int n_img = (int)(((unsigned long long)(unsigned)q * p.magic_hpwp) >> p.shift_hpwp);
-            const int rem = q - n_img * p.hpwp;
-            const int ho = (int)(((unsigned long long)(unsigned)rem * p.magic_wp) >> p.shift_wp);
-            const int wo = rem - ho * p.wp;
-            const bool ok = (q < m) && (ho < p.h) && (wo < p.wd);
+            const bool ok = (okbits2 >> i) & 1u;
             const size_t o = (size_t)q * KS + ch0;
             unsigned pk[2 * NRB];
 #pragma unroll

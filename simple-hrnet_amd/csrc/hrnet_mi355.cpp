@@ -47,8 +47,8 @@ struct ConvOp {
     int algo = 0;          // 0 = generic kernel (kernels.hip), 1 = pipelined LDS-staged 3x3 stride 1 (conv3x3_lds.hip)
     int up = 0;            // 1 + 2a + b: phase (a, b) of a ConvTranspose2d(4, s2, p1) as a 3x3 conv on the input grid
     int ks = 0, slices = 0, ntiles = 0, nch = 0;
-    int fuse_with = -1;    // conv1 of a BasicBlock that also computes this conv2 (conv3x3_lds.hip: bbf_run)
-    bool fused_away = false;  // conv2 of such a block: no launch of its own
+    int fuse_with = -1;    // conv1 of a BasicBlock that can also compute this conv2 (conv3x3_lds.hip: bbf_run)
+    bool fused_away = false;  // conv2 of such a block: skipped in its own launch whenever conv1's launch ran fused
     int64_t w_off = 0, w_bytes = 0, b_off = 0;
     double flops = 0;
 };
@@ -56,6 +56,7 @@ struct ConvOp {
 // a set of independent LDS-staged 3x3 convolutions issued as ONE launch (conv3x3_lds.hip)
 struct Conv3Group {
     std::vector<int> conv_idx;
+    std::vector<int> fused_prob;  // per member: index (within the group) of its fused-BasicBlock descriptor, or -1
     int prob_first = 0;          // index of the group's first descriptor in the device array
     int max_wp = 0;
     int64_t map_capacity = 0;    // blocks at max_batch
@@ -148,6 +149,11 @@ struct hrn_ctx {
     // fused BasicBlocks on the 48-channel branch (conv3x3_lds.hip: bbf_run): bit-identical, 2.5x less HBM traffic on that
     // branch, +2.6 % on the whole pass at 256 crops; HRN_BBF=0 goes back to two launches per block
     bool disable_bbf = getenv("HRN_BBF") && atoi(getenv("HRN_BBF")) == 0;
+    int bbf_tpb_div = getenv("HRN_BBF_TPB_DIV") ? std::max(1, atoi(getenv("HRN_BBF_TPB_DIV"))) : 3;  // a fused tile ~ 3 plain ones
+    // fused only when the call has at least this many 512-pixel tiles (six per CU): measured +2 % at 256 crops of
+    // 384x288 (3541 tiles), -1 % at 64 (885 tiles) and at 20, -5 % at one crop, where the two plain launches with their
+    // smaller tiles spread the work over more CUs
+    int bbf_min_tiles = getenv("HRN_BBF_MIN_TILES") ? atoi(getenv("HRN_BBF_MIN_TILES")) : 1536;
     // 1: convolutions that read the same tensor share one cout-tile width so that they can share a launch (and L2)
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
@@ -338,9 +344,8 @@ struct hrn_ctx {
                     a1.ntiles == 1 && a2.slices == 1 && a2.ntiles == 1 && conv3x3_lds_bbf_ok(tensors[t2].wp)) {
                     convs[i1].fuse_with = i2;
                     convs[i2].fused_away = true;
-                } else {
-                    g2.push_back(i2);
                 }
+                g2.push_back(i2);
                 release(t1[b]);
                 release(xs[b]);
                 xs[b] = t2;
@@ -599,6 +604,14 @@ struct hrn_ctx {
         return t < 1 ? 1 : t;
     }
 
+    // A fusable BasicBlock runs fused (conv1's launch does both convolutions, conv2's launch skips it) when the call is
+    // large enough; both launches decide by the same rule.
+    bool bbf_active(const ConvOp &cv, int nb) const {
+        return (nb * tensors[cv.out_t].hpwp + 511) / 512 >= bbf_min_tiles;
+    }
+    bool fused_now(const ConvOp &cv, int nb) const { return cv.fuse_with >= 0 && bbf_active(cv, nb); }
+    bool skipped(const ConvOp &cv, int nb) const { return cv.fused_away && bbf_active(cv, nb); }
+
     // device-resident descriptors + block maps of the grouped conv launches
     int group_blocks(const Conv3Group &g, int nb, std::vector<int2> *out, bool reverse, bool all_short = false) const {
         struct Ent {
@@ -612,23 +625,25 @@ struct hrn_ctx {
         long one_per_block = 0;
         for (int ci : g.conv_idx) {
             const ConvOp &cv = convs[ci];
+            if (skipped(cv, nb)) continue;
             const Tensor &to = tensors[cv.out_t];
-            const int bmn = cv.fuse_with >= 0 ? 512 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+            const int bmn = fused_now(cv, nb) ? 512 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
             one_per_block += (long)((nb * to.hpwp + bmn - 1) / bmn) * cv.ntiles;
         }
         const bool small = small_tiles && one_per_block < small_below;
         // a fused BasicBlock walks 512-pixel tiles through both convolutions (no small-tile mode): about three
         // ordinary 384-pixel tiles' worth of work each
         auto tile_px = [&](const ConvOp &cv, const Tensor &to) {
-            return cv.fuse_with >= 0 ? 512 : small ? 128 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+            return fused_now(cv, nb) ? 512 : small ? 128 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
         };
         auto tiles_per_block = [&](const ConvOp &cv, int div) {
-            return std::max(1, conv3_tiles_per_block(cv) / (cv.fuse_with >= 0 ? 3 : 1) / div);
+            return std::max(1, conv3_tiles_per_block(cv) / (fused_now(cv, nb) ? bbf_tpb_div : 1) / div);
         };
         auto count_blocks = [&](int div) {
             long total = 0;
             for (int ci : g.conv_idx) {
                 const ConvOp &cv = convs[ci];
+                if (skipped(cv, nb)) continue;
                 const Tensor &to = tensors[cv.out_t];
                 const int bm = tile_px(cv, to);
                 const int mtiles = (nb * to.hpwp + bm - 1) / bm;
@@ -643,9 +658,11 @@ struct hrn_ctx {
         if (lf < 1) lf = 1;
         for (size_t k = 0; k < g.conv_idx.size(); ++k) {
             const ConvOp &cv = convs[g.conv_idx[k]];
+            if (skipped(cv, nb)) continue;
             const Tensor &to = tensors[cv.out_t];
             const int bm = tile_px(cv, to);
-            const bool fused = cv.fuse_with >= 0;
+            const bool fused = fused_now(cv, nb);
+            const int prob = fused ? g.fused_prob[k] : (int)k;
             const int mtiles = (nb * to.hpwp + bm - 1) / bm;
             // Blocks come in two lengths: long ones (fewer pipeline prologues -- a block's first loads have nothing to
             // hide behind) over the first `long_share` of the M tiles, short ones over the rest to fill the tail.
@@ -678,7 +695,7 @@ struct hrn_ctx {
                             // every other launch walks the tensors backwards: a launch starts on what its producer
                             // wrote last, i.e. on the part most likely still in the Infinity Cache
                             if (reverse) mt0 = mtiles - mt0 - tiles;
-                            ents.push_back({key, int2{(int)k | (nt << 8) | (tiles << 16), mt0 | (fused ? 1 << 29 : small ? 1 << 30 : 0)}});
+                            ents.push_back({key, int2{prob | (nt << 8) | (tiles << 16), mt0 | (fused ? 1 << 29 : small ? 1 << 30 : 0)}});
                         }
             }
         }
@@ -769,6 +786,10 @@ struct hrn_ctx {
         for (auto &g : groups) {
             g.prob_first = (int)nprob;
             nprob += g.conv_idx.size();
+            g.fused_prob.assign(g.conv_idx.size(), -1);
+            int extra = (int)g.conv_idx.size();
+            for (size_t k = 0; k < g.conv_idx.size(); ++k)
+                if (convs[g.conv_idx[k]].fuse_with >= 0) g.fused_prob[k] = extra++, ++nprob;  // a second descriptor: the fused form
         }
         if (!nprob) return true;
         std::vector<Conv3Problem> hp(nprob);
@@ -784,16 +805,18 @@ struct hrn_ctx {
                 q.cin = cv.cin, q.cout = cv.cout, q.h = to.h, q.wd = to.w, q.wp = to.wp, q.hpwp = to.hpwp;
                 q.relu = cv.relu, q.slices = cv.slices, q.ntiles = cv.ntiles;
                 q.w2 = nullptr, q.bias2 = nullptr;
-                if (cv.fuse_with >= 0) {  // the whole BasicBlock: in = x (also the residual), out = the block's output
-                    const ConvOp &c2 = convs[cv.fuse_with];
-                    q.out = row0(c2.out_t), q.relu = c2.relu;
-                    q.w2 = blob + c2.w_off, q.bias2 = (const float *)(blob + c2.b_off);
-                }
                 q.tiles_per_block = conv3_tiles_per_block(cv);
                 q.bm = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
                 fast_div(to.hpwp, &q.magic_hpwp, &q.shift_hpwp);
                 fast_div(to.wp, &q.magic_wp, &q.shift_wp);
                 if (to.wp > g.max_wp) g.max_wp = to.wp;
+                if (cv.fuse_with >= 0) {  // the whole BasicBlock: in = x (also the residual), out = the block's output
+                    const ConvOp &c2 = convs[cv.fuse_with];
+                    Conv3Problem &f = hp[g.prob_first + g.fused_prob[k]];
+                    f = q;
+                    f.out = row0(c2.out_t), f.relu = c2.relu, f.res = nullptr;
+                    f.w2 = blob + c2.w_off, f.bias2 = (const float *)(blob + c2.b_off);
+                }
             }
             g.map_capacity = 64 + 4 * (int64_t)std::max(small_below, 256) + 1024;  // one M tile per block = most blocks any split can produce (+ the small-tile mode)
             for (int ci : g.conv_idx) {
@@ -1539,11 +1562,17 @@ int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms
                 if (conv_ms && op.idx < conv_ms_len) conv_ms[op.idx] = ms;
             } else if (op.kind == OP_CONV3_GROUP) {  // one launch, several convs: split by FLOPs
                 const Conv3Group &g = h->groups[op.idx];
-                double tot = 0;  // (a fused BasicBlock's launch carries its conv2 as well)
-                for (int ci : g.conv_idx) tot += h->convs[ci].flops + (h->convs[ci].fuse_with >= 0 ? h->convs[h->convs[ci].fuse_with].flops : 0.0);
+                double tot = 0;  // (a fused BasicBlock's launch carries its conv2 as well, and conv2's launch skips it)
                 for (int ci : g.conv_idx) {
-                    if (conv_ms && ci < conv_ms_len) conv_ms[ci] = (float)(ms * h->convs[ci].flops / tot);
-                    const int c2 = h->convs[ci].fuse_with;
+                    const ConvOp &cv = h->convs[ci];
+                    if (h->skipped(cv, n)) continue;
+                    tot += cv.flops + (h->fused_now(cv, n) ? h->convs[cv.fuse_with].flops : 0.0);
+                }
+                for (int ci : g.conv_idx) {
+                    const ConvOp &cv = h->convs[ci];
+                    if (h->skipped(cv, n)) continue;
+                    if (conv_ms && ci < conv_ms_len) conv_ms[ci] = (float)(ms * cv.flops / tot);
+                    const int c2 = h->fused_now(cv, n) ? cv.fuse_with : -1;
                     if (conv_ms && c2 >= 0 && c2 < conv_ms_len) conv_ms[c2] = (float)(ms * h->convs[c2].flops / tot);
                 }
             } else if (op.kind == OP_CONV_GROUP) {  // likewise; these are latency / bandwidth bound: split by block count
