@@ -146,6 +146,8 @@ struct hrn_ctx {
     bool small_tiles = getenv("HRN_SMALL_TILES") ? atoi(getenv("HRN_SMALL_TILES")) != 0 : true;
     int small_below = getenv("HRN_SMALL_BELOW") ? atoi(getenv("HRN_SMALL_BELOW")) : 384;
     bool disable_chain_ds = getenv("HRN_DISABLE_CHAIN_DS") != nullptr;
+    // generic conv kernel, bf16: the block's weights through LDS instead of one copy per wave from L2 (+1.6 % on the pass)
+    bool direct_wlds = !(getenv("HRN_DIRECT_WLDS") && atoi(getenv("HRN_DIRECT_WLDS")) == 0);
     // fused BasicBlocks on the 48-channel branch (conv3x3_lds.hip: bbf_run): bit-identical, 2.5x less HBM traffic on that
     // branch, +2.6 % on the whole pass at 256 crops; HRN_BBF=0 goes back to two launches per block
     bool disable_bbf = getenv("HRN_BBF") && atoi(getenv("HRN_BBF")) == 0;
@@ -722,6 +724,7 @@ struct hrn_ctx {
         a.m = nb * to.hpwp;
         a.ksize = cv.k, a.stride = cv.stride, a.relu = cv.relu, a.kchunks = cv.kchunks;
         a.rev = rev;
+        a.wlds = direct_wlds && dtype == 1 ? 1 : 0;
         a.up = cv.up ? 1 : 0, a.up_a = cv.up ? (cv.up - 1) >> 1 : 0, a.up_b = cv.up ? (cv.up - 1) & 1 : 0;
         a.up_wp = tensors[cv.out_t].wp, a.up_hpwp = tensors[cv.out_t].hpwp;
         for (int t = 0; t < 4; ++t) {  // live tap t = ty*2 + tx of phase (a, b): dy = ty - 1 + a, dx = tx - 1 + b
@@ -1161,7 +1164,7 @@ struct hrn_ctx {
                         if (e != hipSuccess) break;
                         g.cached_nb = nb;
                     }
-                    e = launch_conv_group(dtype, g.args_dev, g.map_dev, g.nblocks, g.nr, g.mr, s);
+                    e = launch_conv_group(dtype, g.args_dev, g.map_dev, g.nblocks, g.nr, g.mr, direct_wlds && dtype == 1, s);
                     break;
                 }
                 case OP_CHAIN: {

@@ -26,6 +26,7 @@ struct ConvArgs {
     int ksize, stride, relu;
     int kchunks;                            // padded K / (32 bf16 | 16 f32)
     int rev;                                // walk the M tiles backwards (see hrn_ctx::alternate)
+    int wlds;                               // bf16, full-size tiles: weights staged through LDS once per block (kernels.hip: WL)
     // one phase (a, b) of a ConvTranspose2d(4, stride 2, padding 1) run as a 3x3 conv on the input grid: the result of
     // pixel (ho, wo) is stored at (2*ho + a, 2*wo + b) of the twice-as-large tensor (poseresnet.py:84-100)
     int up, up_a, up_b, up_wp, up_hpwp;
@@ -163,7 +164,7 @@ hipError_t launch_tta_decode(const TtaArgs &a, hipStream_t s);
 
 hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s);
 // grouped launch of the generic kernel: device-resident ConvArgs[], block map entries (prob | cout tile << 8, M tile)
-hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr, int mr,
+hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr, int mr, int wlds,
                              hipStream_t s);
 hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb, int ks,
                               int nrb, hipStream_t s);

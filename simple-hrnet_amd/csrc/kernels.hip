@@ -72,13 +72,17 @@ __device__ __forceinline__ f32x4 mma<DT_F32>(f32x4 w, f32x4 x, f32x4 acc) {
 // PRE: the residual is fetched before the K loop instead of after it.  The 1x1 convs of layer1 have K = 64: the
 // loop is two chunks long and the kernel is a chain of memory round trips (operands, residual, store); this folds
 // the first two into one.  bf16, even NR only.
-template <int DT, int NR, int MR, bool PRE = false>
-__device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng, const int mtile_in) {
+// WL: the weights of the block's cout group go through LDS, four K chunks at a time (LDS-DMA, double-buffered, one
+// barrier per four chunks), instead of every wave fetching its own copy from L2 -- a quarter of the weight requests
+// (profiles/round1_pmc_direct.txt: this kernel lives on L2 round trips).
+constexpr int WL_G = 4;
+template <int DT, int NR, int MR, bool PRE = false, bool WL = false>
+__device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng, const int mtile_in, char *smem = nullptr) {
     using T = Tr<DT>;
     using vec = typename T::vec;
     using elem = typename T::elem;
     typedef const GLOBAL_AS vec *gvec_p;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, g = lane >> 4;
     if (mtile_in * 64 * MR >= p.m) return;
     const int mtile = p.rev ? (p.m + 64 * MR - 1) / (64 * MR) - 1 - mtile_in : mtile_in;
@@ -130,10 +134,36 @@ __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng
     const GLOBAL_AS char *__restrict__ wlane =
         (const GLOBAL_AS char *)p.w + ((size_t)ng * NR * p.kchunks * 64 + lane) * 16;
 
+    // WL: stage chunk group gi (chunks gi*WL_G ...) of all NR fragments into buffer gi & 1: NR * WL_G pieces of 1 KiB,
+    // piece t = j * WL_G + c, dealt round-robin to the four waves
+    auto stage = [&](int gi) {
+        const GLOBAL_AS char *wsrc = (const GLOBAL_AS char *)p.w + (size_t)ng * NR * p.kchunks * 1024;
+#pragma unroll
+        for (int t0 = 0; t0 < NR * WL_G; t0 += 4) {
+            const int t = t0 + wave;
+            const int j = t / WL_G, c = gi * WL_G + (t - j * WL_G);
+            if (t < NR * WL_G && c < p.kchunks)
+                __builtin_amdgcn_global_load_lds(wsrc + ((size_t)(j * p.kchunks + c) * 64 + lane) * 16,
+                                                 (__attribute__((address_space(3))) void *)(smem + ((gi & 1) * NR * WL_G + t) * 1024), 16, 0, 0);
+        }
+    };
+    if constexpr (WL) stage(0);
     for (int kc = 0; kc < p.kchunks; ++kc) {
         vec b[NR];
+        if constexpr (WL) {
+            const int gi = kc / WL_G, c = kc - gi * WL_G;
+            if (c == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();  // group gi has landed for everybody; everybody is done with the other buffer
+                if ((gi + 1) * WL_G < p.kchunks) stage(gi + 1);
+            }
+            const char *wl = smem + ((gi & 1) * NR * WL_G + c) * 1024 + lane * 16;
 #pragma unroll
-        for (int j = 0; j < NR; ++j) b[j] = *(gvec_p)(wlane + ((size_t)j * p.kchunks + kc) * 1024);
+            for (int j = 0; j < NR; ++j) b[j] = *(const vec *)(wl + j * WL_G * 1024);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) b[j] = *(gvec_p)(wlane + ((size_t)j * p.kchunks + kc) * 1024);
+        }
         vec a[MR];
         if (tap < ntaps) {
             int tapoff = 0;
@@ -223,52 +253,56 @@ __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng
 // one convolution per launch.  1-D grid, cout tile fastest: the blocks that share an activation tile are dispatched
 // together, so the tile is fetched from HBM once and re-read from L2.  The hardware places block b on XCD b % 8
 // (private L2s): the cout tiles of one M tile are issued 8 ids apart.
-template <int DT, int NR, int MR, bool PRE>
+template <int DT, int NR, int MR, bool PRE, bool WL = false>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_direct[];
     const int ngroups = p.cout / (16 * NR);
     const int ng = (blockIdx.x >> 3) % ngroups;
     const int mtile = (blockIdx.x / (8 * ngroups)) * 8 + (blockIdx.x & 7);
-    conv_direct_body<DT, NR, MR, PRE>(p, ng, mtile);
+    conv_direct_body<DT, NR, MR, PRE, WL>(p, ng, mtile, smem_direct);
 }
 
 // several independent convolutions per launch: block b runs map[b] = (problem | cout tile << 8, M tile) of the
 // device-resident descriptor array (the host orders the map so that convolutions reading the same tensor sit on
 // the same XCD at the same time, hrnet_mi355.cpp: direct_group_blocks)
-template <int DT, int NR, int MR>
+template <int DT, int NR, int MR, bool WL = false>
 __global__ __launch_bounds__(256) void conv_direct_group_kernel(const ConvArgs *__restrict__ probs,
                                                                 const int2 *__restrict__ map) {
+    extern __shared__ __attribute__((aligned(16))) char smem_direct[];
     const int2 e = map[blockIdx.x];
     const int prob = __builtin_amdgcn_readfirstlane(e.x & 255), ng = __builtin_amdgcn_readfirstlane(e.x >> 8);
     const int mtile = __builtin_amdgcn_readfirstlane(e.y);
     const ConvArgs p = probs[prob];
-    conv_direct_body<DT, NR, MR>(p, ng, mtile);
+    conv_direct_body<DT, NR, MR, false, WL>(p, ng, mtile, smem_direct);
 }
 
 template <int DT, int NR>
-static hipError_t launch_conv_group_t(const ConvArgs *probs, const int2 *map, int nblocks, int mr, hipStream_t s) {
+static hipError_t launch_conv_group_t(const ConvArgs *probs, const int2 *map, int nblocks, int mr, int wlds, hipStream_t s) {
     if (mr == 1)
         hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 1>), dim3(nblocks), dim3(256), 0, s, probs, map);
     else if (mr == 2)
         hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 2>), dim3(nblocks), dim3(256), 0, s, probs, map);
+    else if (DT == DT_BF16 && wlds)
+        hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 4, DT == DT_BF16>), dim3(nblocks), dim3(256), 2 * WL_G * NR * 1024, s, probs, map);
     else
         hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 4>), dim3(nblocks), dim3(256), 0, s, probs, map);
     return hipGetLastError();
 }
 
 // mr = 16-pixel fragments per wave (4, 2 or 1): the host shrinks the M tile when a launch would not fill the chip
-hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr, int mr,
+hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr, int mr, int wlds,
                              hipStream_t s) {
     if (nblocks <= 0) return hipSuccess;
     const int2 *map = (const int2 *)map_dev;
     if (dtype == DT_BF16) {
-        if (nr == 6) return launch_conv_group_t<DT_BF16, 6>(probs_dev, map, nblocks, mr, s);
-        if (nr == 4) return launch_conv_group_t<DT_BF16, 4>(probs_dev, map, nblocks, mr, s);
-        if (nr == 3) return launch_conv_group_t<DT_BF16, 3>(probs_dev, map, nblocks, mr, s);
-        if (nr == 2) return launch_conv_group_t<DT_BF16, 2>(probs_dev, map, nblocks, mr, s);
+        if (nr == 6) return launch_conv_group_t<DT_BF16, 6>(probs_dev, map, nblocks, mr, wlds, s);
+        if (nr == 4) return launch_conv_group_t<DT_BF16, 4>(probs_dev, map, nblocks, mr, wlds, s);
+        if (nr == 3) return launch_conv_group_t<DT_BF16, 3>(probs_dev, map, nblocks, mr, wlds, s);
+        if (nr == 2) return launch_conv_group_t<DT_BF16, 2>(probs_dev, map, nblocks, mr, wlds, s);
     } else {
-        if (nr == 4) return launch_conv_group_t<DT_F32, 4>(probs_dev, map, nblocks, mr, s);
-        if (nr == 3) return launch_conv_group_t<DT_F32, 3>(probs_dev, map, nblocks, mr, s);
-        if (nr == 2) return launch_conv_group_t<DT_F32, 2>(probs_dev, map, nblocks, mr, s);
+        if (nr == 4) return launch_conv_group_t<DT_F32, 4>(probs_dev, map, nblocks, mr, wlds, s);
+        if (nr == 3) return launch_conv_group_t<DT_F32, 3>(probs_dev, map, nblocks, mr, wlds, s);
+        if (nr == 2) return launch_conv_group_t<DT_F32, 2>(probs_dev, map, nblocks, mr, wlds, s);
     }
     return hipErrorInvalidValue;
 }
@@ -294,6 +328,13 @@ static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
     const long blocks4 = (long)((a.m + 255) / 256) * ngroups;
     if (blocks4 < 256) return launch_conv_tt<DT, NR, 1, false>(a, s);
     if (blocks4 < 512) return launch_conv_tt<DT, NR, 2, false>(a, s);
+    if constexpr (DT == DT_BF16)
+        if (a.wlds && a.kchunks >= 2 * WL_G) {
+            const int mtiles = (a.m + 255) / 256;
+            dim3 grid(((mtiles + 7) / 8) * 8 * (a.cout / (16 * NR)));
+            hipLaunchKernelGGL((conv_direct_kernel<DT, NR, 4, false, true>), grid, dim3(256), 2 * WL_G * NR * 1024, s, a);
+            return hipGetLastError();
+        }
     return launch_conv_tt<DT, NR, 4, false>(a, s);
 }
 

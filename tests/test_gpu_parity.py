@@ -251,7 +251,7 @@ def test_scheduling_variants_are_bit_identical(pkg, dtype, monkeypatch):
     boxes = pkg.synth_boxes(n, seed=22)
 
     def run(env):
-        for k in ("HRN_DISABLE_DGROUP", "HRN_DISABLE_CHAIN", "HRN_DISABLE_CHAIN_DS", "HRN_BBF", "HRN_BBF_MIN_TILES", "HRN_SMALL_TILES", "HRN_DGROUP_NR", "HRN_ALTERNATE", "HRN_DISABLE_GROUP", "HRN_BLOCK_ORDER",
+        for k in ("HRN_DISABLE_DGROUP", "HRN_DISABLE_CHAIN", "HRN_DISABLE_CHAIN_DS", "HRN_BBF", "HRN_BBF_MIN_TILES", "HRN_DIRECT_WLDS", "HRN_SMALL_TILES", "HRN_DGROUP_NR", "HRN_ALTERNATE", "HRN_DISABLE_GROUP", "HRN_BLOCK_ORDER",
                   "HRN_LONG_FACTOR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -263,7 +263,7 @@ def test_scheduling_variants_are_bit_identical(pkg, dtype, monkeypatch):
         return out
 
     base = run({})
-    for env in ({"HRN_DISABLE_DGROUP": "1"}, {"HRN_DISABLE_CHAIN": "1"}, {"HRN_DISABLE_CHAIN_DS": "1"}, {"HRN_BBF": "0"}, {"HRN_BBF_MIN_TILES": "1"}, {"HRN_SMALL_TILES": "0"}, {"HRN_DGROUP_NR": "0"}, {"HRN_ALTERNATE": "0"}, {"HRN_DISABLE_GROUP": "1"},
+    for env in ({"HRN_DISABLE_DGROUP": "1"}, {"HRN_DISABLE_CHAIN": "1"}, {"HRN_DISABLE_CHAIN_DS": "1"}, {"HRN_BBF": "0"}, {"HRN_BBF_MIN_TILES": "1"}, {"HRN_DIRECT_WLDS": "0"}, {"HRN_SMALL_TILES": "0"}, {"HRN_DGROUP_NR": "0"}, {"HRN_ALTERNATE": "0"}, {"HRN_DISABLE_GROUP": "1"},
                 {"HRN_BLOCK_ORDER": "0", "HRN_LONG_FACTOR": "1"}):
         hm, pts = run(env)
         np.testing.assert_array_equal(hm, base[0], err_msg=str(env))
@@ -288,6 +288,24 @@ def test_fused_basicblock_is_bit_identical(pkg, monkeypatch, h, w, n, mb):
         net.close()
     assert np.isfinite(outs[0][0]).all()
     assert outs[0][2] == 64 and outs[1][2] == 0   # all 32 BasicBlocks of the 48-channel branch went through the fused pass
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("c,h,w,n", [(48, 128, 96, 96), (32, 128, 96, 128), (48, 256, 192, 40)])
+def test_generic_kernel_weights_through_lds_is_bit_identical(pkg, monkeypatch, c, h, w, n):
+    """kernels.hip WL: the generic conv kernel with its weights staged through LDS (full-size tiles only, hence the
+    large batches) against one copy per wave straight from L2: same bits."""
+    crops = torch.from_numpy(pkg.synth_crops(n, h, w, seed=51)).cuda()
+    boxes = pkg.synth_boxes(n, seed=52)
+    outs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("HRN_DIRECT_WLDS", on)
+        net = _engine(pkg, c, h, w, "bf16", max_batch=n, seed=4)
+        hm, pts = net.predict_crops(crops, boxes, return_heatmaps=True)
+        outs.append((hm.cpu().numpy(), pts.cpu().numpy()))
+        net.close()
+    assert np.isfinite(outs[0][0]).all()
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
