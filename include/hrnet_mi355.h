@@ -147,6 +147,13 @@ int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out);
 double hrn_flops_per_crop(hrn_handle h);            /* 2*MAC, convolutions only              */
 int64_t hrn_workspace_bytes(hrn_handle h);
 int hrn_launches_per_pass(hrn_handle h);
+/* Block map of the `group`-th grouped BasicBlock launch for a call of n crops, as the host would upload it (works on
+ * plan-only handles: the CPU tests check that every (conv, cout tile, M tile) is covered exactly once).  Per block six
+ * int32: descriptor, cout tile, M tiles walked, first M tile, pixels per M tile, flags (1 = fused BasicBlock, 2 =
+ * small tiles).  members[d] = convolution index of descriptor d (+ 2^30: the fused form, which also computes
+ * the block's conv2).  Returns the number of blocks (may exceed capacity), -1 for a bad group / n. */
+int hrn_plan_block_map(hrn_handle h, int group, int n, int reverse, int32_t *blocks, int capacity, int32_t *members,
+                       int member_capacity);
 /* per-kernel HIP-event timing of one pass (dominant-kernel roofline in bench.py):
  * runs one micro-batch of n crops and returns, for conv i, its device time in ms. */
 int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms, int conv_ms_len,

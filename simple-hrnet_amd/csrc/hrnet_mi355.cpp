@@ -584,6 +584,7 @@ struct hrn_ctx {
         const int64_t part = (int64_t)max_batch * joints * head_slabs;
         workspace_bytes += part * 8;
         if (plan_only) {
+            index_groups();
             blob = (char *)calloc(1, (size_t)blob_bytes);
             return blob != nullptr;
         }
@@ -615,10 +616,12 @@ struct hrn_ctx {
     bool skipped(const ConvOp &cv, int nb) const { return cv.fused_away && bbf_active(cv, nb); }
 
     // device-resident descriptors + block maps of the grouped conv launches
-    int group_blocks(const Conv3Group &g, int nb, std::vector<int2> *out, bool reverse, bool all_short = false) const {
+    int group_blocks(const Conv3Group &g, int nb, std::vector<int2> *out, bool reverse, bool all_short = false,
+                     std::vector<int> *tile_px_out = nullptr) const {
         struct Ent {
             double key;
             int2 v;
+            int bm;
         };
         std::vector<Ent> ents;
         // Block lengths follow the size of the launch: small batches get shorter blocks (at least ~2 per CU before
@@ -697,11 +700,15 @@ struct hrn_ctx {
                             // every other launch walks the tensors backwards: a launch starts on what its producer
                             // wrote last, i.e. on the part most likely still in the Infinity Cache
                             if (reverse) mt0 = mtiles - mt0 - tiles;
-                            ents.push_back({key, int2{prob | (nt << 8) | (tiles << 16), mt0 | (fused ? 1 << 29 : small ? 1 << 30 : 0)}});
+                            ents.push_back({key, int2{prob | (nt << 8) | (tiles << 16), mt0 | (fused ? 1 << 29 : small ? 1 << 30 : 0)}, bm});
                         }
             }
         }
         std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
+        if (tile_px_out) {
+            tile_px_out->resize(ents.size());
+            for (size_t i = 0; i < ents.size(); ++i) (*tile_px_out)[i] = ents[i].bm;
+        }
         if (out) {
             out->resize(ents.size());
             for (size_t i = 0; i < ents.size(); ++i) (*out)[i] = ents[i].v;
@@ -784,7 +791,8 @@ struct hrn_ctx {
         return true;
     }
 
-    bool setup_groups() {
+    // descriptor numbering of the grouped launches (host only; plan-only handles need it for hrn_plan_block_map)
+    size_t index_groups() {
         size_t nprob = 0;
         for (auto &g : groups) {
             g.prob_first = (int)nprob;
@@ -794,6 +802,11 @@ struct hrn_ctx {
             for (size_t k = 0; k < g.conv_idx.size(); ++k)
                 if (convs[g.conv_idx[k]].fuse_with >= 0) g.fused_prob[k] = extra++, ++nprob;  // a second descriptor: the fused form
         }
+        return nprob;
+    }
+
+    bool setup_groups() {
+        const size_t nprob = index_groups();
         if (!nprob) return true;
         std::vector<Conv3Problem> hp(nprob);
         for (auto &g : groups) {
@@ -1540,6 +1553,30 @@ double hrn_flops_per_crop(hrn_handle h) {
 
 int64_t hrn_workspace_bytes(hrn_handle h) { return h ? h->workspace_bytes : 0; }
 int hrn_launches_per_pass(hrn_handle h) { return h ? (int)h->ops.size() : 0; }
+
+int hrn_plan_block_map(hrn_handle h, int group, int n, int reverse, int32_t *blocks, int capacity, int32_t *members, int member_capacity) {
+    if (!h || n <= 0 || n > h->max_batch) return -1;
+    if (group < 0 || group >= (int)h->groups.size()) return -1;
+    const Conv3Group &g = h->groups[group];
+    std::vector<int2> map;
+    std::vector<int> px;
+    const int nblocks = h->group_blocks(g, n, &map, reverse != 0, false, &px);
+    for (int i = 0; i < nblocks && i < capacity; ++i) {
+        const int x = map[i].x, y = map[i].y;
+        int32_t *o = blocks + (size_t)i * 6;
+        o[0] = x & 0xff, o[1] = (x >> 8) & 0xff, o[2] = x >> 16, o[3] = y & 0x1fffffff, o[4] = px[i],
+        o[5] = ((y >> 29) & 1) | (((y >> 30) & 1) << 1);
+    }
+    int nm = 0;  // descriptor -> convolution: the plain ones first, then the fused forms (conv1's index + 2^30)
+    for (size_t k = 0; k < g.conv_idx.size(); ++k, ++nm)
+        if (nm < member_capacity) members[nm] = g.conv_idx[k];
+    for (size_t k = 0; k < g.conv_idx.size(); ++k)
+        if (g.fused_prob[k] >= 0) {
+            if (g.fused_prob[k] < member_capacity) members[g.fused_prob[k]] = g.conv_idx[k] | (1 << 30);
+            ++nm;
+        }
+    return nblocks;
+}
 
 int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms, int conv_ms_len, float *other_ms,
                      void *stream) {

@@ -146,3 +146,51 @@ def test_fold_and_pack(dtype):
         bias = net.read_blob(info.b_offset, 4 * cout).view(np.float32)
         np.testing.assert_allclose(bias, shift.astype(np.float32), rtol=0, atol=0)
     net.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 20, 64, 200, 256])
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_block_maps_cover_every_tile_exactly_once(n, reverse):
+    """The block maps of the grouped BasicBlock launches (hrnet_mi355.cpp: group_blocks) for W48 384x288: whatever the
+    block lengths, tile sizes (512 / 384 / 128 pixels) and order chosen for a call of n crops, every (conv, cout tile, M
+    tile) is produced exactly once -- by its own launch, or for the 48-channel BasicBlocks by the fused pass of conv1's
+    launch, in which case conv2's launch must not touch it."""
+    net = pkg.NativeHRNet(48, 17, (384, 288), "bf16", max_batch=256, device=-1)
+    infos = net.conv_infos()
+    names = [i.name.decode() for i in infos]
+    lib = net._lib
+    blocks = np.zeros((40000, 6), np.int32)
+    members = np.zeros(64, np.int32)
+    fused_conv1, plain_done, group = set(), {}, 0
+    while True:
+        nb = lib.hrn_plan_block_map(net._h, group, n, reverse, blocks.ctypes.data, len(blocks), members.ctypes.data, len(members))
+        if nb < 0:
+            break
+        assert 0 < nb <= len(blocks)
+        covered = {}
+        for d, nt, tiles, mt0, px, flags in blocks[:nb]:
+            conv, fused = int(members[d]) & ~(1 << 30), bool(int(members[d]) >> 30)
+            i = infos[conv]
+            assert fused == bool(flags & 1) and (px == 512 if fused else px in (512, 384, 128)) and ((flags & 2) != 0) == (px == 128)
+            mtiles = -(-n * (i.out_h + 1) * (i.out_w + 1) // px)
+            assert 0 <= nt < i.cout // (16 * i.nr) and tiles >= 1 and 0 <= mt0 < mtiles
+            cov = covered.setdefault((conv, fused, int(px)), np.zeros((i.cout // (16 * i.nr), mtiles), np.int32))
+            cov[nt, mt0:min(mtiles, mt0 + tiles)] += 1
+        for (conv, fused, px), cov in covered.items():
+            assert (cov == 1).all(), (names[conv], px, np.unique(cov))
+            assert conv not in plain_done, names[conv]            # one tile size, one form per conv and call
+            plain_done[conv] = fused
+            if fused:
+                fused_conv1.add(names[conv])
+        group += 1
+    assert group == 69                                            # 64 BasicBlock launches + layer1's 4 + transition1
+    hot = [k for k, nm in enumerate(names) if ".branches." in nm]
+    big = -(-n * 97 * 73 // 512) >= 1536                          # hrn_ctx::bbf_min_tiles
+    for k in hot:
+        nm = names[k]
+        if nm.endswith("conv2") and nm.replace("conv2", "conv1") in fused_conv1:
+            assert k not in plain_done, nm                        # computed by conv1's fused pass: no blocks of its own
+        else:
+            assert k in plain_done, nm
+    assert len(fused_conv1) == (32 if big else 0)
+    net.close()
