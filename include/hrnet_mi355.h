@@ -154,6 +154,11 @@ int hrn_launches_per_pass(hrn_handle h);
  * the block's conv2).  Returns the number of blocks (may exceed capacity), -1 for a bad group / n. */
 int hrn_plan_block_map(hrn_handle h, int group, int n, int reverse, int32_t *blocks, int capacity, int32_t *members,
                        int member_capacity);
+/* Likewise for the `group`-th grouped launch of the generic kernel: per block three int32 (descriptor, cout tile, M tile;
+ * M tiles past the end are alignment padding and return at once), members[d] = convolution index, *pixels_per_tile =
+ * 64 * (fragments per wave chosen for n). */
+int hrn_plan_direct_map(hrn_handle h, int group, int n, int32_t *blocks, int capacity, int32_t *members, int member_capacity,
+                        int32_t *pixels_per_tile);
 /* per-kernel HIP-event timing of one pass (dominant-kernel roofline in bench.py):
  * runs one micro-batch of n crops and returns, for conv i, its device time in ms. */
 int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms, int conv_ms_len,

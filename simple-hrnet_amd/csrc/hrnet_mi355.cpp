@@ -1578,6 +1578,22 @@ int hrn_plan_block_map(hrn_handle h, int group, int n, int reverse, int32_t *blo
     return nblocks;
 }
 
+int hrn_plan_direct_map(hrn_handle h, int group, int n, int32_t *blocks, int capacity, int32_t *members, int member_capacity,
+                        int32_t *pixels_per_tile) {
+    if (!h || n <= 0 || n > h->max_batch) return -1;
+    if (group < 0 || group >= (int)h->dgroups.size()) return -1;
+    const DirectGroup &g = h->dgroups[group];
+    int mr = 4;  // as run_pass chooses it
+    while (mr > 1 && h->direct_group_blocks(g, n, nullptr, mr) < 512) mr >>= 1;
+    std::vector<int2> map;
+    const int nblocks = h->direct_group_blocks(g, n, &map, mr);
+    for (int i = 0; i < nblocks && i < capacity; ++i)
+        blocks[(size_t)i * 3] = map[i].x & 0xff, blocks[(size_t)i * 3 + 1] = map[i].x >> 8, blocks[(size_t)i * 3 + 2] = map[i].y;
+    for (size_t k = 0; k < g.conv_idx.size() && (int)k < member_capacity; ++k) members[k] = g.conv_idx[k];
+    if (pixels_per_tile) *pixels_per_tile = 64 * mr;
+    return nblocks;
+}
+
 int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms, int conv_ms_len, float *other_ms,
                      void *stream) {
     if (!h) return 1;

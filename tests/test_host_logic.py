@@ -194,3 +194,37 @@ def test_block_maps_cover_every_tile_exactly_once(n, reverse):
             assert k in plain_done, nm
     assert len(fused_conv1) == (32 if big else 0)
     net.close()
+
+
+@pytest.mark.parametrize("c,res,dtype", [(48, (384, 288), "bf16"), (32, (256, 192), "fp32")])
+@pytest.mark.parametrize("n", [1, 5, 64, 256])
+def test_direct_group_maps_cover_every_tile_exactly_once(c, res, dtype, n):
+    """Grouped launches of the generic kernel (hrnet_mi355.cpp: direct_group_blocks): every (conv, cout tile, M tile) once;
+    entries beyond the last M tile are the XCD-alignment padding."""
+    net = pkg.NativeHRNet(c, 17, res, dtype, max_batch=256, device=-1)
+    infos = net.conv_infos()
+    blocks = np.zeros((60000, 3), np.int32)
+    members = np.zeros(256, np.int32)
+    px = ctypes.c_int32(0)
+    group, seen = 0, set()
+    while True:
+        nb = net._lib.hrn_plan_direct_map(net._h, group, n, blocks.ctypes.data, len(blocks), members.ctypes.data, len(members),
+                                          ctypes.byref(px))
+        if nb < 0:
+            break
+        assert 0 < nb <= len(blocks) and px.value in (64, 128, 256)
+        cov = {}
+        for d, ng, mt in blocks[:nb]:
+            i = infos[members[d]]
+            grid_h, grid_w = (i.out_h, i.out_w)
+            mtiles = -(-n * (grid_h + 1) * (grid_w + 1) // px.value)
+            assert 0 <= ng < i.cout // (16 * i.nr) and mt >= 0
+            if mt < mtiles:
+                cov.setdefault(int(members[d]), np.zeros((i.cout // (16 * i.nr), mtiles), np.int32))[ng, mt] += 1
+        for conv, m in cov.items():
+            assert (m == 1).all(), (infos[conv].name, np.unique(m))
+            assert conv not in seen
+            seen.add(conv)
+        group += 1
+    assert group >= 8 and len(seen) >= 2 * group
+    net.close()
