@@ -152,10 +152,10 @@ struct hrn_ctx {
     // branch, +2.6 % on the whole pass at 256 crops; HRN_BBF=0 goes back to two launches per block
     bool disable_bbf = getenv("HRN_BBF") && atoi(getenv("HRN_BBF")) == 0;
     int bbf_tpb_div = getenv("HRN_BBF_TPB_DIV") ? std::max(1, atoi(getenv("HRN_BBF_TPB_DIV"))) : 3;  // a fused tile ~ 3 plain ones
-    // fused only when the call has at least this many 512-pixel tiles (six per CU): measured +2 % at 256 crops of
-    // 384x288 (3541 tiles), -1 % at 64 (885 tiles) and at 20, -5 % at one crop, where the two plain launches with their
-    // smaller tiles spread the work over more CUs
-    int bbf_min_tiles = getenv("HRN_BBF_MIN_TILES") ? atoi(getenv("HRN_BBF_MIN_TILES")) : 1536;
+    // fused only when the call has at least this many 512-pixel tiles (four per CU): measured at 384x288 +2 % at 256
+    // crops (3541 tiles), +1 % at 128-192, +6 % at 96 (1328 tiles), -1 % at 64 (885 tiles), -2 % at 20, -5 % at one crop,
+    // where the two plain launches with their smaller tiles spread the work over more CUs
+    int bbf_min_tiles = getenv("HRN_BBF_MIN_TILES") ? atoi(getenv("HRN_BBF_MIN_TILES")) : 1100;
     // 1: convolutions that read the same tensor share one cout-tile width so that they can share a launch (and L2)
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;

@@ -277,7 +277,7 @@ def test_fused_basicblock_is_bit_identical(pkg, monkeypatch, h, w, n, mb):
     crops = torch.from_numpy(pkg.synth_crops(n, h, w, seed=41)).cuda()
     boxes = pkg.synth_boxes(n, seed=42)
     outs = []
-    monkeypatch.setenv("HRN_BBF_MIN_TILES", "1")   # (by default only calls with >= 1536 tiles of 512 pixels take the fused pass)
+    monkeypatch.setenv("HRN_BBF_MIN_TILES", "1")   # (by default only calls with >= 1100 tiles of 512 pixels take the fused pass)
     for on in (True, False):
         monkeypatch.delenv("HRN_BBF", raising=False)
         if not on:
