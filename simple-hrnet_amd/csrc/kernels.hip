@@ -75,7 +75,10 @@ __device__ __forceinline__ f32x4 mma<DT_F32>(f32x4 w, f32x4 x, f32x4 acc) {
 // WL: the weights of the block's cout group go through LDS, four K chunks at a time (LDS-DMA, double-buffered, one
 // barrier per four chunks), instead of every wave fetching its own copy from L2 -- a quarter of the weight requests
 // (profiles/round1_pmc_direct.txt: this kernel lives on L2 round trips).
-constexpr int WL_G = 4;
+#ifndef HRN_WL_G
+#define HRN_WL_G 4
+#endif
+constexpr int WL_G = HRN_WL_G;
 template <int DT, int NR, int MR, bool PRE = false, bool WL = false>
 __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng, const int mtile_in, char *smem = nullptr) {
     using T = Tr<DT>;
