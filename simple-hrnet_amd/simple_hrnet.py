@@ -11,9 +11,13 @@ different, and why:
 * ``multiperson=False`` needs frames that already have the model resolution: the reference resizes them with
   ``cv2.resize(INTER_CUBIC)`` (``:213-218``), which cannot be pinned here (cv2 is absent);
 * ``dtype`` picks the arithmetic mode of the engine (``"fp32"`` = parity mode, ``"bf16"`` = MFMA bf16);
-* one GPU per process (``device='cuda:N'``); for several use ``dist.ShardedHRNet`` instead of ``DataParallel``.
+* one GPU per process: ``device='cuda:N'`` is that GPU; ``'cuda'`` / ``'cuda:1,2'`` name the job's GPUs and the process takes
+  the one of its ``LOCAL_RANK`` (``resolve_device``); shard the crops with ``dist.ShardedHRNet`` instead of ``DataParallel``.
 """
 from __future__ import annotations
+
+import os
+from typing import Optional
 
 import numpy as np
 import torch
@@ -22,6 +26,32 @@ from .native import NativeHRNet
 
 _MEAN = (0.485, 0.456, 0.406)   # SimpleHRNet.py:171
 _STD = (0.229, 0.224, 0.225)
+
+
+def resolve_device(device, local_rank: Optional[int] = None) -> torch.device:
+    """The reference's device argument (``SimpleHRNet.py:123-139``) mapped onto one-process-per-GPU: ``'cuda:3'`` is that
+    GPU; ``'cuda'`` (all GPUs through DataParallel there) and ``'cuda:1,2'`` (the listed ones) name the set this job runs
+    on, of which THIS process takes the entry of its ``LOCAL_RANK`` (0 when not launched by ``torch.distributed.run``).
+    Anything that is not CUDA raises, as the reference does for a wrong name -- there is no CPU path here."""
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if device is None:
+        return torch.device("cuda", local_rank)
+    if isinstance(device, torch.device):
+        if device.type != "cuda":
+            raise ValueError("the MI355X engine has no CPU path (device=%s)" % device)
+        return torch.device("cuda", local_rank if device.index is None else device.index)
+    name = str(device)
+    if name == "cuda":
+        return torch.device("cuda", local_rank)
+    if name.startswith("cuda:"):
+        try:
+            ids = [int(x) for x in name[5:].split(",")]
+        except ValueError:
+            raise ValueError("Wrong device name.") from None           # SimpleHRNet.py:139
+        if ids and all(i >= 0 for i in ids):
+            return torch.device("cuda", ids[local_rank % len(ids)])
+    raise ValueError("Wrong device name." if name.startswith("cuda") else "the MI355X engine has no CPU path (device=%s)" % name)
 
 
 class SimpleHRNet:
@@ -37,12 +67,7 @@ class SimpleHRNet:
             raise ValueError("Wrong model name.")                                   # SimpleHRNet.py:114
         if enable_tensorrt:
             raise ValueError("TensorRT is an NVIDIA engine; this class IS the native engine on MI355X")
-        if device is None:
-            device = torch.device("cuda:0")
-        device = torch.device(device)
-        if device.type != "cuda":
-            raise ValueError("the MI355X engine has no CPU path (device=%s)" % device)
-        self.device = torch.device("cuda", device.index or 0)
+        self.device = resolve_device(device)
         if multiperson and detector is None:
             raise ValueError("multiperson=True needs detector= (the reference's YOLO wrappers are un-vendored third-party code)")
         self.detector = detector

@@ -46,6 +46,24 @@ def test_constructor_errors_without_gpu():
         S(32, 17, {}, enable_tensorrt=True)
 
 
+def test_device_strings_of_the_reference_map_to_one_gpu_per_process(monkeypatch):
+    from importlib import import_module
+    resolve = import_module("simple-hrnet_amd.simple_hrnet").resolve_device
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert resolve("cuda:3") == torch.device("cuda", 3) and resolve(torch.device("cuda:2")) == torch.device("cuda", 2)
+    assert resolve("cuda") == torch.device("cuda", 0) and resolve(None) == torch.device("cuda", 0)
+    assert resolve("cuda:1,2") == torch.device("cuda", 1)
+    monkeypatch.setenv("LOCAL_RANK", "1")                       # as set by torch.distributed.run
+    assert resolve("cuda") == torch.device("cuda", 1) and resolve("cuda:4,6") == torch.device("cuda", 6)
+    assert resolve("cuda:5") == torch.device("cuda", 5)         # an explicit single GPU is taken literally
+    for bad in ("cuda:x", "cuda:-1", "cuda:"):
+        with pytest.raises(ValueError, match="Wrong device name."):
+            resolve(bad)
+    for cpu in ("cpu", torch.device("cpu")):
+        with pytest.raises(ValueError, match="no CPU path"):
+            resolve(cpu)
+
+
 @pytest.mark.gpu
 def test_predict_single_image_multiperson_equals_reference(tmp_path):
     pkg = load_pkg()
