@@ -150,6 +150,37 @@ def prepath_measure(pkg, net, dev):
             "cpu_pil_crops_per_s": None if cpu is None else round(cpu, 1), "cpu_cores": 1, "bit_identical_to_pil_path": same}
 
 
+def pcie_measure(pkg, net, batch, dev):
+    """Side measurement (never `value`): the same pass fed from pinned HOST memory through NativeHRNet.predict_stream --
+    batch k+1 crosses PCIe on a copy stream while batch k computes -- and, for comparison, upload-then-compute in series."""
+    import torch
+
+    h, w = net.resolution
+    host = [torch.randn((batch, 3, h, w), dtype=torch.float32).pin_memory() for _ in range(2)]
+    boxes = pkg.synth_boxes(batch)
+    reps = 6
+
+    def overlapped():
+        for _ in net.predict_stream(((host[k & 1], boxes) for k in range(reps))):
+            pass
+        torch.cuda.synchronize()
+
+    def serial():
+        for k in range(reps):
+            net.predict_crops(host[k & 1].to(dev, non_blocking=True), boxes)
+        torch.cuda.synchronize()
+
+    res = {}
+    for name, fn in (("overlapped", overlapped), ("serial", serial)):
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        res[name] = reps * batch / (time.perf_counter() - t0)
+    return {"crops_per_s": round(res["overlapped"], 1), "unit": "crops/s", "serial_crops_per_s": round(res["serial"], 1),
+            "workload": "%d batches of %d fp32 crops in pinned host memory (%.0f MB each), uploads on a copy stream behind the "
+                        "previous batch's compute" % (reps, batch, batch * 3 * h * w * 4 / 1e6)}
+
+
 def main():
     a = parse()
     if a.cpu_worker:
@@ -273,6 +304,7 @@ def main():
             }
         if world == 1 and not a.no_prepath:
             out["prepath"] = prepath_measure(pkg, net, dev)
+            out["pcie_inclusive"] = pcie_measure(pkg, net, min(a.batch, a.max_batch), dev)
         if world == 1 and not a.no_cpu_baseline and a.model_name == "HRNet":
             out["cpu_baseline"] = cpu_baseline(a.c, a.height, a.width, a.cpu_seconds)
     if dist:

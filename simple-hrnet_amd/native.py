@@ -204,6 +204,50 @@ class NativeHRNet:
                             "hrn_forward")
         return (hm, pts) if return_heatmaps else pts
 
+    def predict_stream(self, batches, return_heatmaps: bool = False):
+        """Model call + decode for a sequence of HOST-resident batches with the uploads hidden behind the compute:
+        batch k+1 crosses PCIe on a copy stream (two device staging buffers) while batch k runs on the current stream.
+        ``batches``: iterable of ``(images (n,3,H,W) float32 host tensor -- pinned memory for a truly asynchronous copy --,
+        boxes (n,4))`` with ``n <= max_batch``.  Yields, per batch, what ``predict_crops`` returns (results of batch k
+        are ready on the current stream; read them after a synchronize or through ``.cpu()``)."""
+        dev = self.torch_device
+        compute = torch.cuda.current_stream(dev)
+        copy = torch.cuda.Stream(dev)
+        h, w = self.resolution
+        stage = [torch.empty((self.max_batch, 3, h, w), dtype=torch.float32, device=dev) for _ in range(2)]
+        landed = [torch.cuda.Event(), torch.cuda.Event()]
+        consumed = [None, None]
+
+        def upload(slot, item):
+            images, boxes = item
+            if not isinstance(images, torch.Tensor) or images.device.type != "cpu":
+                raise TypeError("predict_stream takes host tensors; device-resident crops go to predict_crops")
+            n = images.shape[0]
+            if n > self.max_batch:
+                raise ValueError("a batch of %d crops exceeds max_batch=%d" % (n, self.max_batch))
+            with torch.cuda.stream(copy):
+                if consumed[slot] is not None:
+                    copy.wait_event(consumed[slot])              # the pass that read this buffer has finished
+                stage[slot][:n].copy_(images.to(torch.float32), non_blocking=True)
+                landed[slot].record(copy)
+            return n, boxes
+
+        it = iter(batches)
+        nxt = next(it, None)
+        pending = upload(0, nxt) if nxt is not None else None
+        k = 0
+        while pending is not None:
+            slot = k & 1
+            n, boxes = pending
+            nxt = next(it, None)
+            pending = upload(slot ^ 1, nxt) if nxt is not None else None   # goes out while this batch computes
+            compute.wait_event(landed[slot])
+            out = self.predict_crops(stage[slot][:n], boxes, return_heatmaps=return_heatmaps)
+            consumed[slot] = torch.cuda.Event()
+            consumed[slot].record(compute)
+            yield out
+            k += 1
+
     # -- introspection --------------------------------------------------------------------------
     def predict_flip_tta(self, images: torch.Tensor, flip_pairs, post_processing: bool = True):
         """Flip test-time augmentation + evaluation decode (``testing/Test.py:132-140``, ``misc/utils.py:9-29, 125-175``):

@@ -372,3 +372,24 @@ def test_other_joint_count_and_two_engines_on_side_streams(pkg, dtype):
         assert err < 0.05 * ref_hm.std() + 0.05, err
         np.testing.assert_array_equal(pts[..., :2], T.decode_heatmaps(hm, boxes)[..., :2])
     a.close(), b.close()
+
+
+def test_predict_stream_hides_uploads_and_matches_predict_crops(pkg):
+    """Host-resident batches through the double-buffered upload pipeline: same results as predict_crops, ragged sizes."""
+    c, h, w = 32, 128, 96
+    net = _engine(pkg, c, h, w, "bf16", max_batch=8, seed=2)
+    sizes = [8, 3, 8, 1, 5]
+    items = []
+    for k, n in enumerate(sizes):
+        x = torch.from_numpy(pkg.synth_crops(n, h, w, seed=60 + k))
+        items.append((x.pin_memory(), pkg.synth_boxes(n, seed=70 + k)))
+    outs = [(hm.cpu().numpy(), pts.cpu().numpy()) for hm, pts in net.predict_stream(iter(items), return_heatmaps=True)]
+    assert len(outs) == len(sizes)
+    for (x, b), (hm, pts) in zip(items, outs):
+        ref_hm, ref_pts = net.predict_crops(x.cuda(), b, return_heatmaps=True)
+        np.testing.assert_array_equal(hm, ref_hm.cpu().numpy())
+        np.testing.assert_array_equal(pts, ref_pts.cpu().numpy())
+    assert list(net.predict_stream(iter([]))) == []
+    with pytest.raises(ValueError):
+        list(net.predict_stream([(torch.zeros((9, 3, h, w)), pkg.synth_boxes(9))]))
+    net.close()
