@@ -64,6 +64,69 @@ def test_device_strings_of_the_reference_map_to_one_gpu_per_process(monkeypatch)
             resolve(cpu)
 
 
+class _FakeEngine:
+    """stands in for NativeHRNet on a box without a GPU: joints encode (running crop number, joint) so that the result
+    assembly of SimpleHRNet.predict -- what is tested here -- can be followed crop by crop"""
+
+    def __init__(self, c, nof_joints, resolution, dtype, max_batch, device, model_name):
+        self.j, self.res, self.count = nof_joints, resolution, 0
+
+    def load_state_dict(self, sd):
+        return self
+
+    def preprocess_frame(self, frame, dets, variant="pad"):
+        assert variant in ("pad", "clamp") and frame.ndim == 3
+        boxes = np.rint(np.asarray(dets, np.float32)[:, :4]).astype(np.int32)
+        return torch.zeros((len(dets), 3) + tuple(self.res)), boxes, torch.from_numpy(boxes)
+
+    def predict_crops(self, images, boxes, return_heatmaps=False):
+        n = images.shape[0]
+        pts = torch.zeros((n, self.j, 3))
+        pts[:, :, 0] = torch.arange(self.count, self.count + n, dtype=torch.float32)[:, None]
+        pts[:, :, 1] = torch.arange(self.j, dtype=torch.float32)[None, :]
+        self.count += n
+        hm = torch.zeros((n, self.j, self.res[0] // 4, self.res[1] // 4))
+        return (hm, pts) if return_heatmaps else pts
+
+    def predict_frame(self, frame, dets, return_heatmaps=False, variant="pad"):
+        images, boxes, boxes_dev = self.preprocess_frame(frame, dets, variant)
+        out = self.predict_crops(images, boxes_dev, return_heatmaps)
+        return (boxes, out[1], out[0]) if return_heatmaps else (boxes, out)
+
+
+def test_result_assembly_follows_the_reference_without_a_gpu(monkeypatch):
+    """SimpleHRNet.py:333-343 / 445-496 on a fake engine: list order, bare-array rule, per-image re-split, empty shapes."""
+    from importlib import import_module
+    mod = import_module("simple-hrnet_amd.simple_hrnet")
+    monkeypatch.setattr(mod, "NativeHRNet", _FakeEngine)
+    frames = np.zeros((4, 60, 80, 3), np.uint8)
+    table = {0: np.asarray([[1, 2, 30, 50], [5, 5, 20, 40]], np.float32), 1: None, 2: np.zeros((0, 4), np.float32),
+             3: np.asarray([[0, 0, 79, 59]], np.float32)}
+    m = mod.SimpleHRNet(32, 17, {}, resolution=(64, 48), multiperson=True, return_heatmaps=True, return_bounding_boxes=True,
+                        detector=TableDetector(table))
+    hm, boxes, pts = m.predict(frames)
+    assert [len(p) for p in pts] == [2, 0, 0, 1] and all(p.shape[1:] == (17, 3) and p.dtype == np.float32 for p in pts)
+    assert [h.shape for h in hm] == [(2, 17, 16, 12), (0, 17, 16, 12), (0, 17, 16, 12), (1, 17, 16, 12)]
+    assert [b.shape for b in boxes] == [(2, 4), (0, 4), (0, 4), (1, 4)]
+    assert pts[0][:, 0, 0].tolist() == [0.0, 1.0] and pts[3][:, 0, 0].tolist() == [2.0]     # crops kept in image order
+    np.testing.assert_array_equal(boxes[3], [[0, 0, 79, 59]])
+    m.return_heatmaps = False
+    boxes, pts = m.predict(frames)
+    assert isinstance(boxes, list) and len(pts) == 4
+    m.return_bounding_boxes = False
+    pts = m.predict(frames)
+    assert isinstance(pts, list) and pts[0].shape == (2, 17, 3)
+    # one image
+    m.return_heatmaps = m.return_bounding_boxes = True
+    hm, boxes, pts = m.predict(frames[0])
+    assert hm.shape == (2, 17, 16, 12) and boxes.shape == (2, 4) and boxes.dtype == np.int32 and pts.shape == (2, 17, 3)
+    m.detector = TableDetector({0: np.zeros((0, 4), np.float32)})
+    hm, boxes, pts = m.predict(frames[0])
+    assert pts.shape == (0, 0, 3) and boxes.shape == (0, 4) and hm.shape == (0, 17, 16, 12)
+    with pytest.raises(ValueError, match="Wrong image format."):
+        m.predict(frames[0, 0])
+
+
 @pytest.mark.gpu
 def test_predict_single_image_multiperson_equals_reference(tmp_path):
     pkg = load_pkg()
