@@ -80,20 +80,17 @@ class SimpleHRNet:
 
     # ------------------------------------------------------------------------------------------ SimpleHRNet.py:174-210
     def predict(self, image):
-        if len(image.shape) == 3:
-            return self._predict_single(image)
-        elif len(image.shape) == 4:
-            return self._predict_batch(image)
+        rank = np.ndim(image)
+        if rank == 3:       # one BGR frame
+            return self._one_frame(image)
+        if rank == 4:       # a stack of frames
+            return self._frame_stack(image)
         raise ValueError("Wrong image format.")
 
     def _result(self, heatmaps, boxes, pts):                                       # :333-343 / :486-496
-        res = []
-        if self.return_heatmaps:
-            res.append(heatmaps)
-        if self.return_bounding_boxes:
-            res.append(boxes)
-        res.append(pts)
-        return res if len(res) > 1 else res[0]
+        wanted = ((self.return_heatmaps, heatmaps), (self.return_bounding_boxes, boxes), (True, pts))
+        out = [value for keep, value in wanted if keep]
+        return out[0] if len(out) == 1 else out
 
     def _normalise(self, images_bgr: np.ndarray) -> torch.Tensor:
         """single-person transform for frames that already have the model resolution: BGR -> RGB, ToTensor, Normalize"""
@@ -113,42 +110,41 @@ class SimpleHRNet:
         return (n, self.nof_joints, self.resolution[0] // 4, self.resolution[1] // 4)
 
     # ------------------------------------------------------------------------------------------ SimpleHRNet.py:212-343
-    def _predict_single(self, image):
+    def _one_frame(self, image):
         if not self.multiperson:
             images = self._normalise(image)
             boxes = np.asarray([[0, 0, image.shape[1], image.shape[0]]], dtype=np.float32)
             hm, pts = self.model.predict_crops(images, boxes, return_heatmaps=True)
             return self._result(hm.cpu().numpy(), boxes, pts.cpu().numpy())
-        detections = self.detector.predict_single(image)
-        nof_people = len(detections) if detections is not None else 0
-        if nof_people == 0:
+        found = self.detector.predict_single(image)
+        if found is None or len(found) == 0:
             return self._result(np.zeros(self._hm_shape(0), np.float32), np.empty((0, 4), np.int32),
                                 np.empty((0, 0, 3), dtype=np.float32))             # :331
-        dets = np.asarray(detections.cpu() if isinstance(detections, torch.Tensor) else detections, np.float32)[:, :4]
+        dets = np.asarray(found.cpu() if isinstance(found, torch.Tensor) else found, np.float32)[:, :4]
         out = self.model.predict_frame(image, dets, return_heatmaps=self.return_heatmaps)
         boxes, pts = out[0], out[1].cpu().numpy()
         hm = out[2].cpu().numpy() if self.return_heatmaps else None
         return self._result(hm, boxes, pts)
 
     # ------------------------------------------------------------------------------------------ SimpleHRNet.py:345-496
-    def _predict_batch(self, images):
+    def _frame_stack(self, images):
         if not self.multiperson:
             x = self._normalise(images)
             boxes = np.repeat(np.asarray([[0, 0, images.shape[2], images.shape[1]]], dtype=np.float32), len(images), axis=0)
             hm, pts = self.model.predict_crops(x, boxes, return_heatmaps=True)
             return self._result(hm.cpu().numpy(), boxes, np.expand_dims(pts.cpu().numpy(), axis=1))   # :475
-        image_detections = self.detector.predict(images)
+        per_frame = self.detector.predict(images)
         crops, boxes = [], []
         counts = []
-        for d, detections in enumerate(image_detections):
-            n = len(detections) if detections is not None else 0
-            counts.append(n if detections is not None else None)
+        for index, found in enumerate(per_frame):
+            n = 0 if found is None else len(found)
+            counts.append(None if found is None else n)
             if n:
-                dets = np.asarray(detections.cpu() if isinstance(detections, torch.Tensor) else detections, np.float32)[:, :4]
-                im, bx, _ = self.model.preprocess_frame(images[d], dets, "clamp")   # :383-412
+                dets = np.asarray(found.cpu() if isinstance(found, torch.Tensor) else found, np.float32)[:, :4]
+                im, bx, _ = self.model.preprocess_frame(images[index], dets, "clamp")   # :383-412
                 crops.append(im), boxes.append(bx)
         if not crops:                                                                # :477-484
-            pts = [np.zeros((0, self.nof_joints, 3), dtype=np.float32) for _ in image_detections]
+            pts = [np.zeros((0, self.nof_joints, 3), dtype=np.float32) for _ in per_frame]
             return self._result(np.zeros(self._hm_shape(0), np.float32), np.asarray([], dtype=np.int32), pts)
         boxes = np.concatenate(boxes, 0)
         out = self.model.predict_crops(torch.cat(crops, 0), boxes, return_heatmaps=self.return_heatmaps)
