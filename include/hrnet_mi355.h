@@ -141,6 +141,25 @@ int hrn_nms(int32_t *keep_out, int32_t *num_out, const float *boxes_host, int bo
             float nms_overlap_thresh, int device_id);
 const char *hrn_nms_last_error(void);
 
+/* ---- pose post-processing on the host (O(people^2 * joints) on a handful of skeletons: host code in the reference,
+ * host code here; numpy's float64 / float32 arithmetic and summation order reproduced) ------------------------------
+ * OKS non-maximum suppression, misc/nms/nms.py:97-122 (`oks_nms`) and :138-180 (`soft_oks_nms`; at most 20 kept, gaussian
+ * rescoring), called per image by datasets/COCO.py:371-374.  kpts: n x J x (x, y, score) float64 (`keypoints.flatten()`),
+ * order: the indices by descending score (`scores.argsort()[::-1]`, done by the caller with numpy as the reference does),
+ * sigmas: J values or NULL for COCO's 17, in_vis_thre: NaN for None.  keep_out (n entries) receives the kept indices. */
+int hrn_oks_nms(int32_t *keep_out, int32_t *num_out, const double *kpts, const double *areas, const int32_t *order, int n, int J,
+                double thresh, const double *sigmas, double in_vis_thre);
+int hrn_soft_oks_nms(int32_t *keep_out, int32_t *num_out, const double *kpts, const double *areas, const double *scores_sorted,
+                     const int32_t *order, int n, int J, double thresh, const double *sigmas, double in_vis_thre);
+/* Tracker, misc/utils.py:372-384 (`compute_similarity_matrices`: box IoU :318-334 and OKS :341-369 of every current
+ * skeleton against every previous one).  boxes: n x (x1, y1, x2, y2) as float64 (exact for the int32 boxes of the
+ * multi-person path), poses: n x J x (y, x, confidence) float32 as predict() returns them; outputs na x nb float32. */
+int hrn_pose_similarity(const double *boxes_a, const float *poses_a, int na, const double *boxes_b, const float *poses_b, int nb, int J,
+                        float *sim_bbox, float *sim_pose);
+/* The optimal assignment `munkres.Munkres().compute(cost)` returns (misc/utils.py:406-407): minimum total cost, every
+ * row matched when rows <= cols, otherwise every column; row_to_col[r] = column or -1. */
+int hrn_assignment(const double *cost, int rows, int cols, int32_t *row_to_col);
+
 /* Introspection used by tests, bench.py and the roofline accounting. */
 int hrn_conv_count(hrn_handle h);
 int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out);

@@ -13,7 +13,9 @@ from . import _lib  # noqa: F401
 from . import synth  # noqa: F401
 from .native import NativeHRNet  # noqa: F401
 from .nms import gpu_nms  # noqa: F401
+from . import postproc  # noqa: F401
+from .postproc import find_person_id_associations, oks_nms, soft_oks_nms  # noqa: F401
 from .simple_hrnet import SimpleHRNet  # noqa: F401
 from .synth import synth_boxes, synth_crops, synth_state_dict  # noqa: F401
 
-__all__ = ["NativeHRNet", "SimpleHRNet", "gpu_nms", "synth", "synth_state_dict", "synth_crops", "synth_boxes"]
+__all__ = ["NativeHRNet", "SimpleHRNet", "gpu_nms", "oks_nms", "soft_oks_nms", "find_person_id_associations", "postproc", "synth", "synth_state_dict", "synth_crops", "synth_boxes"]

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libhrnet_mi355.so")
-SOURCES = ["kernels.hip", "conv3x3_lds.hip", "bottleneck_chain.hip", "prepath.hip", "nms.hip", "hrnet_mi355.cpp"]
+SOURCES = ["kernels.hip", "conv3x3_lds.hip", "bottleneck_chain.hip", "prepath.hip", "nms.hip", "postproc.cpp", "hrnet_mi355.cpp"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(INCLUDE, "hrnet_mi355.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
@@ -95,6 +95,10 @@ SYMBOLS = {
     "hrn_forward_flip_tta": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
     "hrn_nms": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]),
     "hrn_nms_last_error": (ctypes.c_char_p, []),
+    "hrn_oks_nms": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, _P, ctypes.c_double]),
+    "hrn_soft_oks_nms": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, _P, ctypes.c_double]),
+    "hrn_pose_similarity": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "hrn_assignment": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P]),
     "hrn_conv_count": (ctypes.c_int, [_P]),
     "hrn_get_conv_info": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ConvInfo)]),
     "hrn_flops_per_crop": (ctypes.c_double, [_P]),
