@@ -148,6 +148,32 @@ def test_fold_and_pack(dtype):
     net.close()
 
 
+@pytest.mark.parametrize("res,n", [((256, 192), 256), ((256, 192), 150), ((128, 96), 256), ((64, 64), 7)])
+def test_block_maps_cover_every_tile_at_other_resolutions(res, n, monkeypatch):
+    """same invariant at other row pitches, with the fused BasicBlock pass forced on for every call size"""
+    monkeypatch.setenv("HRN_BBF_MIN_TILES", "1")
+    net = pkg.NativeHRNet(48, 17, res, "bf16", max_batch=256, device=-1)
+    infos = net.conv_infos()
+    blocks, members = np.zeros((40000, 6), np.int32), np.zeros(64, np.int32)
+    group, fused_blocks = 0, 0
+    while True:
+        nb = net._lib.hrn_plan_block_map(net._h, group, n, group & 1, blocks.ctypes.data, len(blocks), members.ctypes.data, len(members))
+        if nb < 0:
+            break
+        covered = {}
+        for d, nt, tiles, mt0, px, flags in blocks[:nb]:
+            conv = int(members[d]) & ~(1 << 30)
+            i = infos[conv]
+            mtiles = -(-n * (i.out_h + 1) * (i.out_w + 1) // px)
+            cov = covered.setdefault((conv, int(px)), np.zeros((i.cout // (16 * i.nr), mtiles), np.int32))
+            cov[nt, mt0:min(mtiles, mt0 + tiles)] += 1
+            fused_blocks += int(flags & 1)
+        assert all((cov == 1).all() for cov in covered.values())
+        group += 1
+    assert group == 69 and fused_blocks > 0
+    net.close()
+
+
 @pytest.mark.parametrize("n", [1, 3, 20, 64, 96, 200, 256])
 @pytest.mark.parametrize("reverse", [0, 1])
 def test_block_maps_cover_every_tile_exactly_once(n, reverse):

@@ -21,6 +21,23 @@ def test_resampler_restatement_equals_pillow(h, w, oh, ow):
     np.testing.assert_array_equal(P.pil_bilinear_u8(img, oh, ow), P.pil_resize(img, oh, ow))
 
 
+def test_resampler_restatement_equals_pillow_on_random_sizes():
+    """property test (hypothesis): any input / output size, up- and down-scaling mixed per axis, constant and noisy images"""
+    pytest.importorskip("PIL")
+    hyp = pytest.importorskip("hypothesis")
+    st = hyp.strategies
+
+    @hyp.settings(max_examples=60, deadline=None)
+    @hyp.given(h=st.integers(1, 160), w=st.integers(1, 160), oh=st.integers(1, 96), ow=st.integers(1, 96), seed=st.integers(0, 2 ** 31),
+               flat=st.booleans())
+    def check(h, w, oh, ow, seed, flat):
+        rng = np.random.default_rng(seed)
+        img = np.full((h, w, 3), rng.integers(0, 256), np.uint8) if flat else rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        np.testing.assert_array_equal(P.pil_bilinear_u8(img, oh, ow), P.pil_resize(img, oh, ow))
+
+    check()
+
+
 def test_box_arithmetic():
     # 384x288: target aspect h/w = 4/3
     # tall enough already (cf < 1): pad x.  box 80 x 180 -> cf = 4/3 * 80/180 = 0.5926 -> length = round(80/cf) = 135
