@@ -131,3 +131,52 @@ def find_person_id_associations(boxes, pts, prev_boxes, prev_pts, prev_person_id
     fresh = person_ids == -1
     person_ids[fresh] = np.arange(next_person_id, next_person_id + np.sum(fresh))
     return boxes, pts, person_ids
+
+
+def inverse_affine(center, scale, pixel_std, output_size) -> np.ndarray:
+    """The 2x3 matrix ``get_affine_transform(center, scale, pixel_std, 0, output_size, inv=1)`` returns
+    (``misc/utils.py:44-76``): heat-map coordinates back to image coordinates for an unrotated crop.  The reference builds
+    three float32 point pairs and lets ``cv2.getAffineTransform`` solve for the matrix in float64; the same pairs are built
+    here with the same float32 roundings and the 6x6 system is solved by LU in float64 (``numpy.linalg.solve``)."""
+    scale = np.asarray(scale)
+    if scale.ndim == 0:
+        scale = np.array([scale, scale])
+    scale_tmp = scale * 1.0 * pixel_std
+    src_w, dst_w, dst_h = scale_tmp[0], output_size[0], output_size[1]
+    shift = np.array([0, 0], dtype=np.float32)
+    src, dst = np.zeros((3, 2), dtype=np.float32), np.zeros((3, 2), dtype=np.float32)
+    src[0, :] = center + scale_tmp * shift
+    src[1, :] = center + [0 * 1.0 - (src_w * -0.5) * 0.0, 0 * 0.0 + (src_w * -0.5) * 1.0] + scale_tmp * shift   # get_dir, rot = 0
+    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5]) + np.array([0, dst_w * -0.5], np.float32)
+    for pts in (src, dst):                                   # get_3rd_point: b + (-(a - b).y, (a - b).x)
+        direct = pts[0, :] - pts[1, :]
+        pts[2, :] = pts[1, :] + np.array([-direct[1], direct[0]], dtype=np.float32)
+    a = np.zeros((6, 6), np.float64)
+    b = np.zeros(6, np.float64)
+    for k in range(3):                                       # dst -> src (inv = 1)
+        a[2 * k, 0:3] = (dst[k, 0], dst[k, 1], 1.0)
+        a[2 * k + 1, 3:6] = (dst[k, 0], dst[k, 1], 1.0)
+        b[2 * k], b[2 * k + 1] = src[k, 0], src[k, 1]
+    return np.linalg.solve(a, b).reshape(2, 3)
+
+
+def transform_preds(coords, center, scale, pixel_std, output_size) -> np.ndarray:
+    """``misc/utils.py:116-123``: (J, 2) heat-map coordinates of one crop -> image coordinates, float32.  With the
+    ``preds`` of ``NativeHRNet.predict_flip_tta`` this completes ``get_final_preds`` (``misc/utils.py:154-180``)."""
+    coords = np.asarray(coords.detach().cpu().numpy() if hasattr(coords, "detach") else coords)
+    target = np.zeros(coords.shape, dtype=np.float32)
+    trans = inverse_affine(center, scale, pixel_std, output_size)
+    for p in range(coords.shape[0]):
+        target[p, 0:2] = np.dot(trans, np.array([coords[p, 0], coords[p, 1], 1.]).T)[:2]
+    return target
+
+
+def final_preds(preds, center, scale, pixel_std, heatmap_size) -> np.ndarray:
+    """the "Transform back" loop of ``get_final_preds`` (``misc/utils.py:176-178``) over a batch: preds (n, J, 2) in heat-map
+    pixels (x, y), center / scale (n, 2) as the dataset provides them, heatmap_size = (width, height)."""
+    preds = np.asarray(preds.detach().cpu().numpy() if hasattr(preds, "detach") else preds)
+    out = np.empty(preds.shape, np.float32)
+    for i in range(preds.shape[0]):
+        out[i] = transform_preds(preds[i], center[i], scale[i], pixel_std, heatmap_size)
+    return out

@@ -2,7 +2,8 @@
 ``oks_nms`` / ``soft_oks_nms`` (misc/nms/nms.py:75-180) and the tracker ``find_person_id_associations`` with its
 similarity matrices (misc/utils.py:341-429), produced by IMPORTING THE UNMODIFIED REFERENCE FUNCTIONS in the build
 container.  Stand-ins only for imports that are absent here and are not the code under test: ``cv2`` (unused by these
-functions), the compiled ``cpu_nms`` / ``gpu_nms`` extensions (unused by the OKS functions) and ``munkres`` -- the
+functions except ``getAffineTransform``, for which the stand-in solves the same three-point system in float64), the compiled
+``cpu_nms`` / ``gpu_nms`` extensions (unused by the OKS functions) and ``munkres`` -- the
 reference calls ``Munkres().compute(cost)`` for an optimal assignment; the stand-in returns scipy's
 ``linear_sum_assignment`` of the same matrix (the optimum is unique on these inputs: no tied costs).
 
@@ -32,7 +33,19 @@ def install_stubs():
     m = types.ModuleType("munkres")
     m.Munkres = Munkres
     sys.modules["munkres"] = m
-    sys.modules["cv2"] = types.ModuleType("cv2")
+    cv2 = types.ModuleType("cv2")
+
+    def get_affine_transform(src, dst):
+        """stand-in for cv2.getAffineTransform: the 2x3 matrix mapping three points onto three points, float64 LU solve"""
+        a, b = np.zeros((6, 6)), np.zeros(6)
+        for k in range(3):
+            a[2 * k, 0:3] = (src[k, 0], src[k, 1], 1.0)
+            a[2 * k + 1, 3:6] = (src[k, 0], src[k, 1], 1.0)
+            b[2 * k], b[2 * k + 1] = dst[k, 0], dst[k, 1]
+        return np.linalg.solve(a, b).reshape(2, 3)
+
+    cv2.getAffineTransform = get_affine_transform
+    sys.modules["cv2"] = cv2
     for name in ("cpu_nms", "gpu_nms"):
         mod = types.ModuleType(name)
         setattr(mod, name, lambda *a, **k: (_ for _ in ()).throw(RuntimeError("not under test")))
@@ -114,6 +127,18 @@ def main():
             out["oks%d_%s" % (k, name)] = v
         nms_cases.append(k)
     out["oks_cases"] = np.asarray(nms_cases, np.int32)
+    # ---- inverse affine of the evaluation decode (misc/utils.py:116-123, 176-178): transform_preds per crop
+    import torch
+    centers, scales, coords, sizes, results = [], [], [], [], []
+    for k in range(12):
+        w, h = (72, 96) if k % 2 else (48, 64)
+        center = rng.uniform(50, 900, 2).astype(np.float32)
+        scale = (np.array([rng.uniform(40, 400) / 200, rng.uniform(40, 600) / 200], dtype=np.float32) * 1.25).astype(np.float32)
+        c = np.stack([rng.uniform(0, w, 17), rng.uniform(0, h, 17)], 1).astype(np.float32)
+        centers.append(center), scales.append(scale), coords.append(c), sizes.append((w, h))
+        results.append(U.transform_preds(torch.from_numpy(c), center, scale, 200, [w, h]).numpy())
+    out.update(affine_center=np.stack(centers), affine_scale=np.stack(scales), affine_coords=np.stack(coords),
+               affine_size=np.asarray(sizes, np.int32), affine_out=np.stack(results))
     path = os.path.join(HERE, "tracking_cases.npz")
     np.savez_compressed(path, **out)
     print("wrote %s (%.1f KB): %d tracker cases, %d OKS-NMS cases" % (path, os.path.getsize(path) / 1024, len(cases), len(nms_cases)))

@@ -83,3 +83,20 @@ def test_empty_sides():
     b, p = pp.compute_similarity_matrices(np.zeros((0, 4), np.int32), np.zeros((2, 4), np.int32), np.zeros((0, 17, 3), np.float32),
                                           np.zeros((2, 17, 3), np.float32))
     assert b.shape == (0, 2) and p.shape == (0, 2)
+
+
+def test_inverse_affine_of_the_evaluation_decode_equals_reference():
+    """transform_preds (misc/utils.py:116-123): equal to the reference's function on the fixture, and to the closed form an
+    unrotated crop has (uniform scale src_w / dst_w about the centre) within a float32 ulp of the coordinate."""
+    for k in range(len(G["affine_out"])):
+        center, scale, coords = G["affine_center"][k], G["affine_scale"][k], G["affine_coords"][k]
+        w, h = (int(v) for v in G["affine_size"][k])
+        got = pp.transform_preds(coords, center, scale, 200, [w, h])
+        assert got.dtype == np.float32
+        np.testing.assert_array_equal(got, G["affine_out"][k])
+        s = float(scale[0]) * 200 / w
+        closed = np.stack([(coords[:, 0].astype(np.float64) - w * 0.5) * s + float(center[0]),
+                           (coords[:, 1].astype(np.float64) - h * 0.5) * s + float(center[1])], 1)
+        assert np.abs(closed - got).max() < 2e-4
+    batch = pp.final_preds(G["affine_coords"][[1, 3]], G["affine_center"][[1, 3]], G["affine_scale"][[1, 3]], 200, [72, 96])
+    np.testing.assert_array_equal(batch, G["affine_out"][[1, 3]])
