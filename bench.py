@@ -6,19 +6,30 @@
 Metric (BASELINE.json): person-crops/sec, HRNet-W48 384x288, batch 256 per GPU, bf16 MFMA with fp32
 accumulate, synthetic crops already resident in HBM, random-init (seeded) weights.  One "step" = one pass
 of the hot path over one batch of 256 crops per GPU: stem -> stage1-4 -> head -> arg-max decode ->
-(N>1) all-gather of the keypoints.  N>1: one process per GPU under torch.distributed.run, RCCL backend;
-crops are sharded by contiguous index ranges (weak scaling: 256 crops per GPU), the packed weights are
-broadcast once from rank 0, and the only per-step collective is the all-gather of 204 B/crop of joints.
+(N>1) all-gather of the keypoints.  N>1: one process per GPU, RCCL backend; crops are sharded by contiguous
+index ranges (weak scaling: 256 crops per GPU), the packed weights are broadcast once from rank 0, and the only
+per-step collective is the all-gather of 204 B/crop of joints.  `python bench.py --gpus N` spawns its own N
+ranks (re-executes itself under torch.distributed.run) when it was not started by a launcher; started BY a
+launcher (RANK / WORLD_SIZE in the environment) it is one of the ranks.
 
-Prints ONE JSON line on rank 0 (fields per the driver contract, plus `roofline` and `cpu_baseline`).
+Prints ONE JSON line on rank 0: the driver-contract fields plus
+  roofline      dominant kernel (stage-3/4 BasicBlock 3x3 convs) against the dense bf16 MFMA peak, HIP-event timed
+  parity        N=1: the first 32 crops of the TIMED batch against the CPU oracle (fp32 engine: identical coordinates;
+                bf16 engine: arg-max agreement and pixel histogram)
+  cpu_baseline  N=1: the reference's device='cpu' path restated (oracle), max_batch_size=32 chunks, on this box's cores
+  clip          N=1: BASELINE configs[4] -- 30 synthetic 1080p frames x 8 detector boxes, frame -> crops -> joints
+  config1_fp32  N=1: BASELINE configs[1] -- HRNet-W32 256x192, batch 64, fp32, against the fp32 MFMA peak
+  prepath, pcie_inclusive   side measurements
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import importlib
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,6 +38,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PEAK_F32_TFLOPS = 157.3     # fp32 MFMA = vector rate
+PARITY_CROPS = 32           # = one max_batch_size chunk of the reference (SimpleHRNet.py:285-294)
 
 
 def parse():
@@ -43,35 +55,64 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("HRN_MAX_BATCH", "256")),
                     help="crops per internal pass (workspace size)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline AND parity (both need the CPU oracle)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-prepath", action="store_true", help="skip the crop pre-path side measurement")
-    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-prepath", action="store_true", help="skip the crop pre-path / PCIe side measurements")
+    ap.add_argument("--no-clip", action="store_true", help="skip the configs[4] clip block")
+    ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] fp32 side line")
+    ap.add_argument("--clip", action="store_true", help="ONLY the configs[4] clip measurement (its JSON line is the clip block)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def _cpu_worker(c, h, w, budget_s):
-    """child process body of cpu_baseline(): prints one JSON line"""
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU legs (child process): the oracle restates the reference's device='cpu' path; it is the CHECKER and the reported
+# CPU baseline, never part of what is timed on the GPU.
+def _host_cpu():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    logical = os.cpu_count() or 1
+    quota = logical
+    try:  # container CPU quota (cgroup v2): threads beyond it only thrash
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, min(logical, int(int(q) / int(period))))
+    except Exception:
+        pass
+    return model, logical, quota
+
+
+def _cpu_worker(spec_path):
+    """child process body: prints one JSON line.  spec: {c,h,w,budget_s, crops (npy path or None), boxes, out (npz path),
+    clip: {...} or None}"""
+    import numpy as np
     import torch
 
+    spec = json.load(open(spec_path))
     pkg = importlib.import_module("simple-hrnet_amd")
     from oracle import hrnet_torch_oracle as T
 
+    c, h, w, budget_s = spec["c"], spec["h"], spec["w"], spec["budget_s"]
     sd = pkg.synth.to_torch_state_dict(pkg.synth_state_dict(c, 17, 0))
-    crops = torch.from_numpy(pkg.synth_crops(8, h, w))
-    boxes = pkg.synth_boxes(8)
-    cores = os.cpu_count() or 1
-    try:  # container CPU quota (cgroup v2): threads beyond it only thrash
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            cores = max(1, min(cores, int(int(quota) / int(period))))
-    except Exception:
-        pass
+    chunk = PARITY_CROPS
+    if spec.get("crops"):
+        crops = torch.from_numpy(np.load(spec["crops"]))
+        boxes = np.asarray(spec["boxes"], np.int32)
+    else:
+        crops = torch.from_numpy(pkg.synth_crops(chunk, h, w))
+        boxes = pkg.synth_boxes(chunk)
+    model, logical, quota = _host_cpu()
     # one thread per logical CPU collapses oneDNN on big SMT hosts; probe a few thread counts on two crops
     # and keep the fastest (the count actually used is reported as `cores`)
     best, best_t = None, 1e30
-    for nt in sorted({min(cores, x) for x in (8, 16, 32, 64, 128)}):
+    for nt in sorted({min(quota, x) for x in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(nt)
         T.predict_crops(sd, crops[:1], boxes[:1])          # warm-up (primitive cache)
         t0 = time.perf_counter()
@@ -82,42 +123,188 @@ def _cpu_worker(c, h, w, budget_s):
         if dt > budget_s / 2:
             break
     torch.set_num_threads(best)
-    done, t0 = 0, time.perf_counter()
+    # the sample: whole max_batch_size = 32 chunks (the reference's chunk loop, SimpleHRNet.py:285-294) of the same
+    # workload until the budget is spent; the first chunk's outputs are the parity reference
+    done, t0, first = 0, time.perf_counter(), None
     while True:
-        T.predict_crops(sd, crops, boxes)
-        done += 8
+        hm, pts = T.predict_crops(sd, crops, boxes, max_batch_size=chunk)
+        if first is None:
+            first = (hm, pts)
+        done += len(crops)
         el = time.perf_counter() - t0
-        if el >= budget_s or done >= 256:
+        if el >= budget_s or done >= 512:
             break
-    print(json.dumps({"value": round(done / el, 3), "unit": "crops/s", "cores": best, "kind": "port",
-                      "sample": "%d crops (batches of 8) of HRNet-W%d %dx%d fp32 incl. decode, torch-CPU "
-                                "restatement of the reference device='cpu' path (oracle/hrnet_torch_oracle.py), "
-                                "%d threads (container quota %d CPUs of %d logical), %.1f s" % (done, c, h, w, best, cores, os.cpu_count() or 1, el)}))
+    if spec.get("out"):
+        np.savez(spec["out"], hm=first[0], pts=first[1])
+    res = {"value": round(done / el, 3), "unit": "crops/s", "cores": best, "kind": "port", "cpu": model,
+           "sample": "%d crops (max_batch_size=%d chunks, SimpleHRNet.py:285-294) of HRNet-W%d %dx%d fp32 incl. decode, "
+                     "torch-CPU restatement of the reference device='cpu' path (oracle/hrnet_torch_oracle.py; /root/reference "
+                     "does not exist on the GPU box), %d threads (container quota %d CPUs of %d logical), %.1f s"
+                     % (done, chunk, c, h, w, best, quota, logical, el)}
+    clip = spec.get("clip")
+    if clip:  # the reference's per-frame loop (SimpleHRNet.py:228-308): PIL crop/pad/resize per person, model, decode
+        from oracle import prepath_oracle as P
+
+        frame = np.load(clip["frame"])
+        dets = np.asarray(clip["dets"], np.float32)
+        t0 = time.perf_counter()
+        images, bx = P.prepath(frame, dets, h, w, resize=P.pil_resize)
+        _, cpts = T.predict_crops(sd, torch.from_numpy(images), bx, max_batch_size=chunk)
+        el = time.perf_counter() - t0
+        np.savez(clip["out"], pts=cpts, boxes=bx)
+        res["clip"] = {"fps": round(1.0 / el, 4), "persons_per_s": round(len(dets) / el, 3), "frames": 1,
+                       "sample": "1 frame x %d people through the PIL pre-path + model + decode, %d threads" % (len(dets), best)}
+    print(json.dumps(res))
 
 
-def cpu_baseline(c, h, w, budget_s):
-    """The reference's device='cpu' path restated (same ATen/oneDNN ops the reference dispatches), timed on
-    this box's host cores on a bounded sample of the same workload.  Runs in a child process under a hard
-    timeout so that a pathological host cannot eat the GPU box's time."""
+def _run_cpu_worker(spec, budget_s):
     import subprocess
 
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--c", str(c), "--height", str(h),
-           "--width", str(w), "--cpu-seconds", str(budget_s)]
+    fd, path = tempfile.mkstemp(suffix=".json", prefix="hrn_cpu_")
+    with os.fdopen(fd, "w") as f:
+        json.dump(spec, f)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", path]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s * 6 + 60)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s * 8 + 120)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:  # timeout or failure: report it, never block the GPU number
         return {"value": None, "unit": "crops/s", "cores": os.cpu_count(), "kind": "port",
                 "sample": "cpu baseline did not finish: %s" % type(e).__name__}
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def source_hash():
+    """hash of the kernel / host sources a counter reading belongs to (the GPU box has no .git)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "simple-hrnet_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(a, nb):
+    """HBM-side bytes per grouped launch from the committed PMC passes (counters cannot be read from inside the process).
+    Only a reading taken on EXACTLY these sources is quoted; anything else is reported as null with the reason."""
+    import glob
+
+    if not (a.c == 48 and a.dtype == "bf16" and nb == 256 and (a.height, a.width) == (384, 288)):
+        return None, "no PMC reading for this configuration"
+    cur = source_hash()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+        except Exception:
+            continue
+        if j.get("source_hash") == cur:
+            return j["traffic_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, sources %s)" % (os.path.basename(path), cur)
+        stale = stale or os.path.basename(path)
+    return None, "stale: %s was taken on other sources than %s -- re-run tools/pmc_traffic.sh" % (stale, cur) if stale else "no PMC reading committed"
+
+
+def make_clip(seed=7, frames=30, people=8, hf=1080, wf=1920):
+    """BASELINE configs[4]: a seeded synthetic 1080p clip and, per frame, `people` boxes in the detector's (P, 7) format
+    (x1, y1, x2, y2, conf, cls_conf, cls_pred -- models_/detectors/YOLOv3.py:79-141), standing upright, inside the frame."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    clip = rng.integers(0, 256, (frames, hf, wf, 3), dtype=np.uint8)
+    dets = np.zeros((frames, people, 7), np.float32)
+    for f in range(frames):
+        for i in range(people):
+            bh = rng.integers(hf * 5 // 18, hf * 5 // 6)           # 300..900 px tall on a 1080p frame
+            bw = int(bh * rng.uniform(0.3, 0.6))
+            x1, y1 = rng.uniform(0, wf - bw - 1), rng.uniform(0, hf - bh - 1)
+            dets[f, i] = (x1, y1, x1 + bw, y1 + bh, 0.9, 0.9, 0.0)
+    return clip, dets
+
+
+def run_clip(net, clip_host, dets, mode="per_frame", rank=0, world=1):
+    """frame (uint8, pinned host) -> HBM once -> hrn_preprocess_frame -> hrn_forward -> joints.  `per_frame`: the live
+    loop (scripts/live-demo.py:93-162 minus the camera and the detector network), frames dealt round-robin to the ranks,
+    everything asynchronous on one stream, ONE read-back of all joints at the end; `per_frame_sync`: the same with the
+    204 B/person read back after every frame (what a display loop needs); `stacked`: SimpleHRNet.predict on the 4-D
+    stack -- every frame's crops packed into one batch (SimpleHRNet.py:345-443).  Returns (pts (F,P,J,3) numpy with
+    zeros for other ranks' frames, seconds)."""
+    import numpy as np
+    import torch
+
+    dev = net.torch_device
+    nf, people = dets.shape[0], dets.shape[1]
+    mine = [f for f in range(nf) if f % world == rank]
+    out = torch.zeros((nf, people, net.nof_joints, 3), dtype=torch.float32, device=dev)
+    host = np.zeros((nf, people, net.nof_joints, 3), np.float32)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    if mode == "stacked":
+        crops, boxes = [], []
+        for f in mine:
+            im, _, bdev = net.preprocess_frame(clip_host[f].to(dev, non_blocking=True), dets[f], "clamp")
+            crops.append(im), boxes.append(bdev)
+        if crops:
+            pts = net.predict_crops(torch.cat(crops, 0), torch.cat(boxes, 0))
+            out[mine] = pts.view(len(mine), people, net.nof_joints, 3)
+        host = out.cpu().numpy()
+    else:
+        for f in mine:
+            _, pts = net.predict_frame(clip_host[f].to(dev, non_blocking=True), dets[f])
+            if mode == "per_frame_sync":
+                host[f] = pts.cpu().numpy()
+            else:
+                out[f] = pts
+        if mode != "per_frame_sync":
+            host = out.cpu().numpy()
+    torch.cuda.synchronize(dev)
+    return host, time.perf_counter() - t0
+
+
+def clip_measure(pkg, net, dist, rank, world, cpu_clip=None):
+    import numpy as np
+    import torch
+
+    clip, dets = make_clip()
+    clip_host = torch.from_numpy(clip).pin_memory()
+    res = {"workload": "BASELINE configs[4]: %d synthetic %dx%d uint8 frames, %d boxes per frame in the detector's (P,7) format; "
+                       "per frame: upload once -> crop/pad/resize/normalise on the GPU -> HRNet-W%d %dx%d %s -> decode -> 204 B/person "
+                       "back (the detector network itself is out of scope, SURVEY.md 8)" %
+                       (clip.shape[0], clip.shape[1], clip.shape[2], dets.shape[1], net.c, net.resolution[0], net.resolution[1], net.dtype),
+           "n_gpus": world, "frames": int(clip.shape[0]), "persons": int(dets.shape[0] * dets.shape[1])}
+    ref = None
+    for mode in ("per_frame", "per_frame_sync", "stacked"):
+        run_clip(net, clip_host, dets, mode, rank, world)                      # warm-up (allocator, block maps)
+        if dist:
+            dist.barrier()
+        pts, el = run_clip(net, clip_host, dets, mode, rank, world)
+        if dist:
+            t = torch.tensor([el], device=net.torch_device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        res[mode] = {"fps": round(clip.shape[0] / el, 2), "persons_per_s": round(dets.shape[0] * dets.shape[1] / el, 1),
+                     "ms_per_frame": round(el / clip.shape[0] * 1e3, 3)}
+        if mode == "per_frame":
+            ref = pts
+        elif mode == "per_frame_sync" and ref is not None:
+            res["per_frame_sync"]["same_joints_as_per_frame"] = bool(np.array_equal(pts, ref))
+    res["fps"] = res["per_frame"]["fps"]
+    if cpu_clip and "fps" in cpu_clip and rank == 0:
+        res["cpu_reference_loop"] = {k: cpu_clip[k] for k in ("fps", "persons_per_s", "frames", "sample")}
+        res["speedup_vs_cpu_loop"] = round(res["fps"] / cpu_clip["fps"], 1)
+    return res, (clip, dets, ref)
 
 
 def prepath_measure(pkg, net, dev):
     """Side measurement (not part of `value`): the crop pre-path of SimpleHRNet.py:236-278 on a synthetic 1080p frame
-    with 16 people -- GPU kernel (frame resident in HBM) vs the reference's PIL transform on one host core, same boxes."""
+    with 16 people: GPU kernel, frame resident in HBM."""
     import numpy as np
     import torch
-    from oracle import prepath_oracle as P
 
     rng = np.random.default_rng(5)
     hf, wf, people = 1080, 1920, 16
@@ -130,7 +317,7 @@ def prepath_measure(pkg, net, dev):
         dets[i] = (x1, y1, x1 + bw, y1 + bh)
     fdev = torch.from_numpy(frame).to(dev)
     for _ in range(3):
-        images, boxes, _ = net.preprocess_frame(fdev, dets)
+        net.preprocess_frame(fdev, dets)
     torch.cuda.synchronize()
     reps = 20
     t0 = time.perf_counter()
@@ -139,15 +326,8 @@ def prepath_measure(pkg, net, dev):
     torch.cuda.synchronize()
     gpu = reps * people / (time.perf_counter() - t0)
     h, w = net.resolution
-    try:
-        t0 = time.perf_counter()
-        ref_images, ref_boxes = P.prepath(frame, dets, h, w, resize=P.pil_resize)
-        cpu = people / (time.perf_counter() - t0)
-        same = bool(np.array_equal(images.cpu().numpy(), ref_images) and np.array_equal(boxes, ref_boxes))
-    except Exception:  # Pillow missing
-        cpu, same = None, None
-    return {"crops_per_s": round(gpu, 1), "unit": "crops/s", "workload": "1920x1080 uint8 frame resident in HBM, 16 people, crop+pad+resize+normalise to %dx%d" % (h, w),
-            "cpu_pil_crops_per_s": None if cpu is None else round(cpu, 1), "cpu_cores": 1, "bit_identical_to_pil_path": same}
+    return {"crops_per_s": round(gpu, 1), "unit": "crops/s",
+            "workload": "1920x1080 uint8 frame resident in HBM, 16 people, crop+pad+resize+normalise to %dx%d" % (h, w)}
 
 
 def pcie_measure(pkg, net, batch, dev):
@@ -181,19 +361,120 @@ def pcie_measure(pkg, net, batch, dev):
                         "previous batch's compute" % (reps, batch, batch * 3 * h * w * 4 / 1e6)}
 
 
+def config1_measure(pkg, dev):
+    """BASELINE configs[1]: HRNet-W32 256x192, batch 64 random crops, one GPU, fp32 (exact-fp32 MFMA) -- the parity mode."""
+    import torch
+
+    c, h, w, n = 32, 256, 192, 64
+    net = pkg.NativeHRNet(c, 17, (h, w), "fp32", max_batch=n, device=dev.index).load_state_dict(pkg.synth_state_dict(c, 17, 0))
+    g = torch.Generator(device=dev).manual_seed(77)
+    images = torch.randn((n, 3, h, w), generator=g, device=dev, dtype=torch.float32)
+    boxes = torch.from_numpy(pkg.synth_boxes(n, seed=77)).to(dev)
+    for _ in range(2):
+        net.predict_crops(images, boxes)
+    torch.cuda.synchronize()
+    steps = 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        net.predict_crops(images, boxes)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    value = steps * n / el
+    flops = net.flops_per_crop()
+    conv_ms, other = net.profile_pass(images)
+    conv_ms, other = net.profile_pass(images)
+    tf = value * flops / 1e12
+    conv_tf = sum(i.flops for i in net.conv_infos()) * n / (sum(conv_ms) * 1e-3) / 1e12
+    net.close()
+    return {"workload": "HRNet-W32 256x192, batch=64 random crops, fp32 (v_mfma_f32_16x16x4_f32), model forward + decode (BASELINE configs[1])",
+            "value": round(value, 1), "unit": "crops/s", "ms_per_step": round(el / steps * 1e3, 3), "dtype": "f32",
+            "gflop_per_crop": round(flops / 1e9, 3), "whole_net_tflops": round(tf, 2),
+            "roofline": {"bound": "mfma", "kernel": "all convolutions of the pass (generic MFMA kernel, fp32)", "achieved": round(conv_tf, 2),
+                         "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tf / PEAK_F32_TFLOPS, 4),
+                         "whole_net_frac": round(tf / PEAK_F32_TFLOPS, 4),
+                         "timing": "HIP events on the launch stream around every kernel of one pass of 64 crops"}}
+
+
+def parity_measure(pkg, net, a, images, boxes, dev, cpu_out):
+    """The first PARITY_CROPS crops of the timed batch, taken from a full-batch call (the batch-256 code path itself),
+    against the CPU oracle's outputs for the same crops (computed by the cpu_baseline worker)."""
+    import numpy as np
+    import torch
+
+    k = min(PARITY_CROPS, a.batch)
+    ref = np.load(cpu_out)
+    ref_hm, ref_pts = ref["hm"][:k], ref["pts"][:k]
+    hm, pts = net.predict_crops(images, boxes, return_heatmaps=True)      # whole batch, as timed
+    hm, pts = hm[:k].cpu().numpy(), pts[:k].cpu().numpy()
+    del ref
+    hw = ref_hm.shape[-1]
+    flat, rflat = hm.reshape(k, hm.shape[1], -1), ref_hm.reshape(k, hm.shape[1], -1)
+    am, ram = flat.argmax(-1), rflat.argmax(-1)
+    cells = np.maximum(np.abs(am // hw - ram // hw), np.abs(am % hw - ram % hw))
+    px = cells * 4                                                        # heat-map cell = 4 px of the crop
+    edges = [0, 4, 8, 16, 32]
+    hist = {"0": int((px == 0).sum())}
+    for lo, hi in zip(edges, edges[1:]):
+        hist["%d-%d" % (lo + 1, hi)] = int(((px > lo) & (px <= hi)).sum())
+    hist[">32"] = int((px > 32).sum())
+    out = {"subset": "first %d crops of the timed batch, results taken from the full batch-%d call (micro-batch %d)" % (k, a.batch, a.max_batch),
+           "reference": "CPU oracle (oracle/hrnet_torch_oracle.py = the reference's device='cpu' path), fp32",
+           "%s_argmax_agree_frac" % a.dtype: round(float((am == ram).mean()), 4),
+           "%s_px_hist" % a.dtype: hist, "%s_px_unit" % a.dtype: "crop pixels, max(|dy|,|dx|) per (crop, joint), %d joints" % am.size,
+           "%s_max_abs_dH" % a.dtype: round(float(np.abs(hm - ref_hm).max()), 5), "heatmap_sigma": round(float(ref_hm.std()), 4),
+           "%s_coords_identical" % a.dtype: bool(np.array_equal(pts[..., :2], ref_pts[..., :2]))}
+    if a.dtype != "fp32" and a.model_name == "HRNet":   # the parity mode on the same crops
+        f32 = pkg.NativeHRNet(a.c, 17, (a.height, a.width), "fp32", max_batch=k, device=dev.index).load_state_dict(pkg.synth_state_dict(a.c, 17, 0))
+        hm32, pts32 = f32.predict_crops(images[:k], boxes[:k], return_heatmaps=True)
+        hm32, pts32 = hm32.cpu().numpy(), pts32.cpu().numpy()
+        f32.close()
+        out["fp32_coords_identical"] = bool(np.array_equal(pts32[..., :2], ref_pts[..., :2]))
+        out["fp32_max_abs_dH"] = float(np.abs(hm32 - ref_hm).max())
+        out["fp32_max_coord_dev_px"] = float(np.abs(pts32[..., :2] - ref_pts[..., :2]).max())
+    return out
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU over RCCL) and relay rank 0's line."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit("--gpus %d but only %d GPU(s) visible" % (a.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / device-memory sharing across processes
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        sys.stdout.write(r.stdout)
+        raise SystemExit("the %d-rank run failed (exit code %d)" % (a.gpus, r.returncode))
+    print(lines[-1], flush=True)
+
+
 def main():
     a = parse()
     if a.cpu_worker:
-        return _cpu_worker(a.c, a.height, a.width, a.cpu_seconds)
+        return _cpu_worker(a.cpu_worker)
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if a.gpus > 1 and not launched:
+        return self_launch(a)
+    import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -212,10 +493,21 @@ def main():
     eng = shard.ShardedHRNet(net, dist)
     eng.load_and_broadcast(pkg.synth_state_dict(a.c, 17, 0, model=a.model_name) if rank == 0 else None, src=0)
 
+    if a.clip:   # only the configs[4] measurement
+        cpu = None
+        res, _ = clip_measure(pkg, net, dist, rank, world, cpu)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"clip": res}), flush=True)
+        return
+
     # synthetic crops, device resident (post-normalisation domain ~N(0,1)), different per rank
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn((a.batch, 3, a.height, a.width), generator=g, device=dev, dtype=torch.float32)
-    boxes = torch.from_numpy(pkg.synth_boxes(a.batch, seed=100 + rank)).to(dev)
+    boxes_np = pkg.synth_boxes(a.batch, seed=100 + rank)
+    boxes = torch.from_numpy(boxes_np).to(dev)
 
     def step():
         return eng.predict_crops_local_then_gather(images, boxes)
@@ -230,14 +522,20 @@ def main():
     for _ in range(a.steps):
         pts = step()
     torch.cuda.synchronize()
+    el_mine = time.perf_counter() - t0     # this rank's own loop (before the closing barrier)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    per_rank = [a.batch * a.steps / el_mine]
     if dist:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+        mine = torch.tensor([a.batch * a.steps / el_mine], device=dev, dtype=torch.float64)
+        allr = torch.empty((world,), device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank = [float(x) for x in allr.cpu()]
     assert tuple(pts.shape) == (a.batch * world, 17, 3) and bool(torch.isfinite(pts).all())
 
     out = None
@@ -246,18 +544,22 @@ def main():
         value = crops_total / el
         flops = net.flops_per_crop()
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        name = "HRNet-W%d" % a.c if a.model_name == "HRNet" else "PoseResNet-%d" % a.c
         out = {
-            "metric": "person-crops/sec %s %dx%d (model forward + heat-map decode)"
-                      % ("HRNet-W%d" % a.c if a.model_name == "HRNet" else "PoseResNet-%d" % a.c, a.height, a.width),
+            "metric": "person-crops/sec %s %dx%d (model forward + heat-map decode)" % (name, a.height, a.width),
             "value": round(value, 2), "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "%s %dx%d, batch=%d random crops per GPU, %s%s"
-                                   % ("HRNet-W%d" % a.c if a.model_name == "HRNet" else "PoseResNet-%d" % a.c, a.height, a.width,
-                                      a.batch, a.dtype, " MFMA (BASELINE configs[2])" if (a.model_name, a.c, a.dtype) == ("HRNet", 48, "bf16") else ""),
+                                   % (name, a.height, a.width, a.batch, a.dtype,
+                                      " MFMA (BASELINE configs[2])" if (a.model_name, a.c, a.dtype, world) == ("HRNet", 48, "bf16", 1)
+                                      else " MFMA, sharded over %d GPUs (BASELINE configs[3] shape: %d crops per step)" % (world, a.batch * world)
+                                      if (a.model_name, a.c, a.dtype) == ("HRNet", 48, "bf16") else ""),
                        "global_batch": a.batch * world, "micro_batch": a.max_batch,
                        "parallelism": "dp%d (crop sharding, RCCL all-gather of keypoints)" % world,
                        "weights": "random-init seeded (synth_state_dict seed 0), BN stats randomised"},
+            "rccl_ranks": world if dist else 0,
+            "per_rank_crops_per_s": [round(x, 1) for x in per_rank],
             "whole_net_tflops": round(value / world * flops / 1e12, 2),
             "gflop_per_crop": round(flops / 1e9, 3),
         }
@@ -271,9 +573,11 @@ def main():
             # every branch of a stage module is ONE grouped launch: count launches by (module, block, conv) key.
             sub = [(i, ms) for i, ms in zip(infos, conv_ms)
                    if b".branches." in i.name and (i.name.startswith(b"stage3") or i.name.startswith(b"stage4"))]
+
             def _group(name):
                 f = name.decode().split(".")     # stageX.M.branches.B.K.convN
                 return (f[0], f[1], f[4], f[5])
+
             launches = len({_group(i.name) for i, _ in sub})
             sub_flops = sum(i.flops for i, _ in sub) * nb
             sub_ms = sum(ms for _, ms in sub)
@@ -281,13 +585,7 @@ def main():
             # algorithmic HBM bytes of the same launches: input + output (+ residual) activations and the weights
             esz = 2 if a.dtype == "bf16" else 4
             sub_bytes = sum(((2 + i.has_residual) * i.cout * i.out_h * i.out_w * nb + 9 * i.cin * i.cout) * esz for i, _ in sub)
-            # HBM-side traffic of the same kernel from the committed PMC passes (cannot be collected live)
-            traffic, traffic_src = None, None
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-            if a.c == 48 and a.dtype == "bf16" and nb == 256 and (a.height, a.width) == (384, 288) and os.path.exists(pmc):
-                with open(pmc) as f:
-                    traffic = json.load(f)["traffic_bytes_per_launch"]
-                traffic_src = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            traffic, traffic_src = pmc_traffic(a, nb)
             all_ms = sum(conv_ms) + sum(other.values())
             out["roofline"] = {
                 "bound": "mfma",
@@ -301,12 +599,53 @@ def main():
                 "timing": "HIP events on the launch stream around every kernel of one pass of %d crops" % nb,
                 "subset_share_of_pass_time": round(sub_ms / all_ms, 3),
                 "pass_ms": {"convs": round(sum(conv_ms), 3), **{k: round(v, 3) for k, v in other.items()}},
+                "source_hash": source_hash(),
             }
+        cpu = None
+        tmpdir = tempfile.mkdtemp(prefix="hrn_bench_")
+        if world == 1 and not a.no_cpu_baseline and a.model_name == "HRNet":
+            k = min(PARITY_CROPS, a.batch)
+            spec = {"c": a.c, "h": a.height, "w": a.width, "budget_s": a.cpu_seconds, "crops": os.path.join(tmpdir, "crops.npy"),
+                    "boxes": boxes_np[:k].tolist(), "out": os.path.join(tmpdir, "ref.npz"), "clip": None}
+            np.save(spec["crops"], images[:k].cpu().numpy())
+            if not a.no_clip:
+                clip, dets = make_clip()
+                np.save(os.path.join(tmpdir, "frame0.npy"), clip[0])
+                spec["clip"] = {"frame": os.path.join(tmpdir, "frame0.npy"), "dets": dets[0, :, :4].tolist(), "out": os.path.join(tmpdir, "clip_ref.npz")}
+                del clip
+            cpu = _run_cpu_worker(spec, a.cpu_seconds)
+            if os.path.exists(spec["out"]):
+                try:
+                    out["parity"] = parity_measure(pkg, net, a, images, boxes, dev, spec["out"])
+                except Exception as e:   # never lose the GPU number to the checker
+                    out["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not a.no_clip and a.model_name == "HRNet":
+            try:
+                res, (clip, dets, gpu_pts) = clip_measure(pkg, net, None, 0, 1, (cpu or {}).get("clip"))
+                ref_path = os.path.join(tmpdir, "clip_ref.npz")
+                if os.path.exists(ref_path):   # frame 0 against the reference loop restated on the CPU (bf16 engine: agreement rate)
+                    ref = np.load(ref_path)
+                    h4 = net.resolution[0] // 4
+                    res["frame0_boxes_identical_to_cpu_loop"] = bool(np.array_equal(net.preprocess_frame(clip[0], dets[0])[1], ref["boxes"]))
+                    res["frame0_joints_agree_frac"] = round(float((np.abs(gpu_pts[0][..., :2] - ref["pts"][..., :2]).max(-1) <
+                                                                   (ref["boxes"][:, 3] - ref["boxes"][:, 1]).reshape(-1, 1) / h4 * 0.5).mean()), 4)
+                out["clip"] = res
+            except Exception as e:
+                out["clip"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not a.no_config1 and a.model_name == "HRNet":
+            try:
+                out["config1_fp32"] = config1_measure(pkg, dev)
+            except Exception as e:
+                out["config1_fp32"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not a.no_prepath:
             out["prepath"] = prepath_measure(pkg, net, dev)
             out["pcie_inclusive"] = pcie_measure(pkg, net, min(a.batch, a.max_batch), dev)
-        if world == 1 and not a.no_cpu_baseline and a.model_name == "HRNet":
-            out["cpu_baseline"] = cpu_baseline(a.c, a.height, a.width, a.cpu_seconds)
+        if cpu is not None:
+            cpu.pop("clip", None)
+            out["cpu_baseline"] = cpu
+        import shutil
+
+        shutil.rmtree(tmpdir, ignore_errors=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -165,6 +165,11 @@ int hrn_conv_count(hrn_handle h);
 int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out);
 double hrn_flops_per_crop(hrn_handle h);            /* 2*MAC, convolutions only              */
 int64_t hrn_workspace_bytes(hrn_handle h);
+/* Block maps / descriptor arrays built and uploaded since the handle was created.  They depend on the micro-batch size
+ * only; the handle keeps the four most recent sizes, so a call pattern that alternates a few sizes (every predict() whose
+ * n is not a multiple of max_batch: SimpleHRNet.py:285-294 runs a short last chunk) stops rebuilding after its first
+ * pass over each size -- the test of that property reads this counter. */
+int64_t hrn_map_rebuilds(hrn_handle h);
 int hrn_launches_per_pass(hrn_handle h);
 /* Block map of the `group`-th grouped BasicBlock launch for a call of n crops, as the host would upload it (works on
  * plan-only handles: the CPU tests check that every (conv, cout tile, M tile) is covered exactly once).  Per block six

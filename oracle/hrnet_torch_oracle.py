@@ -16,7 +16,7 @@ The reference's arithmetic lives in PyTorch itself (nn.Conv2d / BatchNorm2d /
 ReLU / Upsample -> ATen -> oneDNN on CPU), so this restatement walks the
 ``state_dict`` with the same ``torch.nn.functional`` primitives in the same
 order; on CPU fp32 it reproduces the reference bit-for-bit (pinned by
-tests/test_oracle_vs_reference.py against the real ``models_.hrnet.HRNet`` when
+tests/test_oracle.py against the real ``models_.hrnet.HRNet`` when
 /root/reference is present, and by the committed fixtures in tests/golden/
 everywhere else).  Parity status: the reference ships no tests or golden
 vectors of its own -- the pin is "outputs of the reference

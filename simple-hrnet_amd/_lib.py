@@ -103,6 +103,7 @@ SYMBOLS = {
     "hrn_get_conv_info": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ConvInfo)]),
     "hrn_flops_per_crop": (ctypes.c_double, [_P]),
     "hrn_workspace_bytes": (ctypes.c_int64, [_P]),
+    "hrn_map_rebuilds": (ctypes.c_int64, [_P]),
     "hrn_launches_per_pass": (ctypes.c_int, [_P]),
     "hrn_plan_block_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int]),
     "hrn_plan_direct_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, _P]),

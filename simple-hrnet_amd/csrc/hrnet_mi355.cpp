@@ -53,6 +53,22 @@ struct ConvOp {
     double flops = 0;
 };
 
+// Block maps (and, for the generic kernel, the descriptors) depend on the micro-batch size nb.  A call whose n is not a
+// multiple of max_batch alternates two sizes, a serving loop a few more: every grouped launch keeps kMapSlots device
+// copies keyed by nb (least recently used one replaced), each with its own PINNED host image and an event, so that
+// (a) a steady mix of sizes uploads nothing, (b) the async H2D never reads pageable or short-lived memory, (c) a pinned
+// image is only rewritten once its previous upload has completed.
+constexpr int kMapSlots = 4;
+struct MapSlot {
+    int nb = -1;
+    int nblocks = 0;
+    int mr = 4;                  // generic kernel: 16-pixel fragments per wave of this map
+    int2 *dev = nullptr, *pin = nullptr;
+    ConvArgs *args_dev = nullptr, *args_pin = nullptr;  // generic kernel only
+    hipEvent_t landed = nullptr;
+    uint64_t stamp = 0;
+};
+
 // a set of independent LDS-staged 3x3 convolutions issued as ONE launch (conv3x3_lds.hip)
 struct Conv3Group {
     std::vector<int> conv_idx;
@@ -60,24 +76,17 @@ struct Conv3Group {
     int prob_first = 0;          // index of the group's first descriptor in the device array
     int max_wp = 0;
     int64_t map_capacity = 0;    // blocks at max_batch
-    int2 *map_dev = nullptr;
-    std::vector<int2> map_host;
-    int cached_nb = -1;
-    int nblocks = 0;
+    MapSlot slot[kMapSlots];
+    std::vector<int2> map_host;  // scratch of group_blocks()
 };
 
 // a set of independent convolutions on the generic kernel issued as ONE launch (kernels.hip: conv_direct_group_kernel)
 struct DirectGroup {
     std::vector<int> conv_idx;
     int nr = 0;
-    ConvArgs *args_dev = nullptr;
-    int2 *map_dev = nullptr;
     int64_t map_capacity = 0;
-    std::vector<ConvArgs> args_host;
-    std::vector<int2> map_host;
-    int cached_nb = -1;
-    int nblocks = 0;
-    int mr = 4;  // 16-pixel fragments per wave of the current map (4, 2 or 1)
+    MapSlot slot[kMapSlots];
+    std::vector<int2> map_host;  // scratch of direct_group_blocks()
 };
 
 struct FuseOp {
@@ -175,6 +184,15 @@ struct hrn_ctx {
     size_t pre_tmp_bytes = 0;
     CropParams *pre_params = nullptr;
     int pre_params_cap = 0;
+    // pinned host image of one call's crop parameters + boxes (the async uploads read it after the call returned);
+    // kPreRing images in rotation, each rewritten only after the upload that last read it has completed
+    static constexpr int kPreRing = 4;
+    char *pre_pin[kPreRing] = {nullptr, nullptr, nullptr, nullptr};
+    size_t pre_pin_bytes[kPreRing] = {0, 0, 0, 0};
+    hipEvent_t pre_landed[kPreRing] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned pre_ring_next = 0;
+    uint64_t map_clock = 0;     // LRU stamp of the block-map slots
+    int64_t map_builds = 0;     // block maps built + uploaded since creation (hrn_map_rebuilds)
     float *tta_hm = nullptr;  // flip-TTA: heat-maps of the mirrored micro-batch (allocated on first use)
     int64_t workspace_bytes = 0;
 
@@ -782,13 +800,50 @@ struct hrn_ctx {
         for (auto &g : dgroups) {
             // M tiles shrink (mr 4 -> 2 -> 1) only while a launch has fewer than 512 blocks: 4x that bounds every case
             g.map_capacity = std::max<int64_t>(direct_group_blocks(g, max_batch, nullptr), 4 * 512 + 64 * (int64_t)g.conv_idx.size() * 8);
-            if (!hip_ok(hipMalloc((void **)&g.map_dev, (size_t)g.map_capacity * sizeof(int2)), "hipMalloc(blockmap)"))
-                return false;
-            if (!hip_ok(hipMalloc((void **)&g.args_dev, g.conv_idx.size() * sizeof(ConvArgs)), "hipMalloc(conv args)"))
-                return false;
-            workspace_bytes += g.map_capacity * (int64_t)sizeof(int2) + (int64_t)(g.conv_idx.size() * sizeof(ConvArgs));
+            for (MapSlot &sl : g.slot) {
+                if (!alloc_slot(sl, g.map_capacity, g.conv_idx.size())) return false;
+                workspace_bytes += g.map_capacity * (int64_t)sizeof(int2) + (int64_t)(g.conv_idx.size() * sizeof(ConvArgs));
+            }
         }
         return true;
+    }
+
+    bool alloc_slot(MapSlot &sl, int64_t capacity, size_t nargs) {
+        if (!hip_ok(hipMalloc((void **)&sl.dev, (size_t)capacity * sizeof(int2)), "hipMalloc(blockmap)")) return false;
+        if (!hip_ok(hipHostMalloc((void **)&sl.pin, (size_t)capacity * sizeof(int2), hipHostMallocDefault), "hipHostMalloc(blockmap)"))
+            return false;
+        if (nargs) {
+            if (!hip_ok(hipMalloc((void **)&sl.args_dev, nargs * sizeof(ConvArgs)), "hipMalloc(conv args)")) return false;
+            if (!hip_ok(hipHostMalloc((void **)&sl.args_pin, nargs * sizeof(ConvArgs), hipHostMallocDefault), "hipHostMalloc(conv args)"))
+                return false;
+        }
+        return hip_ok(hipEventCreateWithFlags(&sl.landed, hipEventDisableTiming), "hipEventCreate");
+    }
+    void free_slot(MapSlot &sl) {
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        if (sl.args_dev) (void)hipFree(sl.args_dev);
+        if (sl.args_pin) (void)hipHostFree(sl.args_pin);
+        if (sl.landed) (void)hipEventDestroy(sl.landed);
+        sl = MapSlot();
+    }
+    // the slot holding the maps of micro-batch size nb, or the least recently used one to rebuild (*hit = false); a
+    // slot about to be rebuilt has had its previous upload waited for, so its pinned image may be rewritten
+    MapSlot *find_slot(MapSlot (&slots)[kMapSlots], int nb, bool *hit) {
+        MapSlot *lru = &slots[0];
+        for (MapSlot &sl : slots) {
+            if (sl.nb == nb) {
+                sl.stamp = ++map_clock;
+                *hit = true;
+                return &sl;
+            }
+            if (sl.stamp < lru->stamp) lru = &sl;
+        }
+        *hit = false;
+        if (lru->nb >= 0) (void)hipEventSynchronize(lru->landed);
+        lru->nb = -1;
+        lru->stamp = ++map_clock;
+        return lru;
     }
 
     // descriptor numbering of the grouped launches (host only; plan-only handles need it for hrn_plan_block_map)
@@ -841,9 +896,10 @@ struct hrn_ctx {
                 const int bm = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
                 g.map_capacity += (int64_t)((max_batch * to.hpwp + bm - 1) / bm) * cv.ntiles;
             }
-            if (!hip_ok(hipMalloc((void **)&g.map_dev, (size_t)g.map_capacity * sizeof(int2)), "hipMalloc(blockmap)"))
-                return false;
-            workspace_bytes += g.map_capacity * (int64_t)sizeof(int2);
+            for (MapSlot &sl : g.slot) {
+                if (!alloc_slot(sl, g.map_capacity, 0)) return false;
+                workspace_bytes += g.map_capacity * (int64_t)sizeof(int2);
+            }
         }
         if (!hip_ok(hipMalloc((void **)&probs_dev, nprob * sizeof(Conv3Problem)), "hipMalloc(problems)")) return false;
         return hip_ok(hipMemcpy(probs_dev, hp.data(), nprob * sizeof(Conv3Problem), hipMemcpyHostToDevice),
@@ -865,10 +921,13 @@ struct hrn_ctx {
             if (part_idx) (void)hipFree(part_idx);
             if (probs_dev) (void)hipFree(probs_dev);
             for (auto &g : groups)
-                if (g.map_dev) (void)hipFree(g.map_dev);
-            for (auto &g : dgroups) {
-                if (g.map_dev) (void)hipFree(g.map_dev);
-                if (g.args_dev) (void)hipFree(g.args_dev);
+                for (MapSlot &sl : g.slot) free_slot(sl);
+            for (auto &g : dgroups)
+                for (MapSlot &sl : g.slot) free_slot(sl);
+            for (int k = 0; k < kPreRing; ++k) {
+                if (pre_pin[k]) (void)hipHostFree(pre_pin[k]);
+                if (pre_landed[k]) (void)hipEventDestroy(pre_landed[k]);
+                pre_pin[k] = nullptr, pre_landed[k] = nullptr, pre_pin_bytes[k] = 0;
             }
         }
         blob = nullptr;
@@ -1150,34 +1209,40 @@ struct hrn_ctx {
                 }
                 case OP_CONV3_GROUP: {
                     Conv3Group &g = groups[op.idx];
-                    if (g.cached_nb != nb) {  // block map depends on the micro-batch size: rebuild on change
-                        g.nblocks = group_blocks(g, nb, &g.map_host, rev);
-                        e = hipMemcpyAsync(g.map_dev, g.map_host.data(), (size_t)g.nblocks * sizeof(int2),
-                                           hipMemcpyHostToDevice, s);
+                    bool hit;
+                    MapSlot *sl = find_slot(g.slot, nb, &hit);
+                    if (!hit) {  // block map depends on the micro-batch size: build it once per size (kMapSlots sizes kept)
+                        sl->nblocks = group_blocks(g, nb, &g.map_host, rev);
+                        memcpy(sl->pin, g.map_host.data(), (size_t)sl->nblocks * sizeof(int2));
+                        e = hipMemcpyAsync(sl->dev, sl->pin, (size_t)sl->nblocks * sizeof(int2), hipMemcpyHostToDevice, s);
+                        if (e == hipSuccess) e = hipEventRecord(sl->landed, s);
                         if (e != hipSuccess) break;
-                        g.cached_nb = nb;
+                        sl->nb = nb;
+                        ++map_builds;
                     }
-                    e = launch_conv3x3_lds(probs_dev + g.prob_first, g.map_dev, g.nblocks, nb, convs[g.conv_idx[0]].ks,
+                    e = launch_conv3x3_lds(probs_dev + g.prob_first, sl->dev, sl->nblocks, nb, convs[g.conv_idx[0]].ks,
                                            convs[g.conv_idx[0]].nr, s);
                     break;
                 }
                 case OP_CONV_GROUP: {
                     DirectGroup &g = dgroups[op.idx];
-                    if (g.cached_nb != nb) {  // descriptors (row counts) and block map depend on the micro-batch size
-                        g.args_host.clear();
-                        for (int ci : g.conv_idx) g.args_host.push_back(conv_args(convs[ci], nb, rev));
-                        g.mr = 4;  // shorter M tiles for small launches: fill the chip, shorten the serial K loop per block
-                        while (g.mr > 1 && direct_group_blocks(g, nb, nullptr, g.mr) < 512) g.mr >>= 1;
-                        g.nblocks = direct_group_blocks(g, nb, &g.map_host, g.mr);
-                        e = hipMemcpyAsync(g.args_dev, g.args_host.data(), g.args_host.size() * sizeof(ConvArgs),
-                                           hipMemcpyHostToDevice, s);
+                    bool hit;
+                    MapSlot *sl = find_slot(g.slot, nb, &hit);
+                    if (!hit) {  // descriptors (row counts) and block map depend on the micro-batch size
+                        for (size_t k = 0; k < g.conv_idx.size(); ++k) sl->args_pin[k] = conv_args(convs[g.conv_idx[k]], nb, rev);
+                        sl->mr = 4;  // shorter M tiles for small launches: fill the chip, shorten the serial K loop per block
+                        while (sl->mr > 1 && direct_group_blocks(g, nb, nullptr, sl->mr) < 512) sl->mr >>= 1;
+                        sl->nblocks = direct_group_blocks(g, nb, &g.map_host, sl->mr);
+                        memcpy(sl->pin, g.map_host.data(), (size_t)sl->nblocks * sizeof(int2));
+                        e = hipMemcpyAsync(sl->args_dev, sl->args_pin, g.conv_idx.size() * sizeof(ConvArgs), hipMemcpyHostToDevice, s);
+                        if (e == hipSuccess)
+                            e = hipMemcpyAsync(sl->dev, sl->pin, (size_t)sl->nblocks * sizeof(int2), hipMemcpyHostToDevice, s);
+                        if (e == hipSuccess) e = hipEventRecord(sl->landed, s);
                         if (e != hipSuccess) break;
-                        e = hipMemcpyAsync(g.map_dev, g.map_host.data(), (size_t)g.nblocks * sizeof(int2),
-                                           hipMemcpyHostToDevice, s);
-                        if (e != hipSuccess) break;
-                        g.cached_nb = nb;
+                        sl->nb = nb;
+                        ++map_builds;
                     }
-                    e = launch_conv_group(dtype, g.args_dev, g.map_dev, g.nblocks, g.nr, g.mr, direct_wlds && dtype == 1, s);
+                    e = launch_conv_group(dtype, sl->args_dev, sl->dev, sl->nblocks, g.nr, sl->mr, direct_wlds && dtype == 1, s);
                     break;
                 }
                 case OP_CHAIN: {
@@ -1290,8 +1355,8 @@ int hrn_create_model(hrn_handle *out, int model, int c, int nof_joints, int heig
         g_create_error = "PoseResNet: c is the ResNet size, 50 / 101 / 152 (the reference's 18 / 34 cannot run: modules.py:50)";
         return 2;
     }
-    if (model == HRN_MODEL_HRNET && (c < 16 || c % 16 != 0)) {
-        g_create_error = "c must be a positive multiple of 16 (HRNet-W32 / W48)";
+    if (model == HRN_MODEL_HRNET && (c <= 0 || (c % 32 != 0 && c % 48 != 0))) {
+        g_create_error = "c must be a positive multiple of 32 or of 48 (HRNet-W32 / W48 / W64 ...): the kernels tile output channels by 32 / 48 / 64";
         return 2;
     }
     if (height <= 0 || width <= 0 || height % 32 || width % 32) {
@@ -1325,6 +1390,15 @@ int hrn_create_model(hrn_handle *out, int model, int c, int nof_joints, int heig
         }
     }
     h->build_plan();
+    // every conv launcher covers cout in tiles of 16*nr channels: a width that leaves a remainder would silently skip
+    // channels (c = 80: 16 of branch 0's 80).  Multiples of 32 and of 48 never do.
+    for (const ConvOp &cv : h->convs)
+        if (cv.nr <= 0 || cv.cout % (16 * cv.nr) != 0) {
+            g_create_error = "unsupported width: convolution '" + cv.conv + "' has " + std::to_string(cv.cout) +
+                             " output channels, not a multiple of its " + std::to_string(16 * cv.nr) +
+                             "-channel tile (use a width that is a multiple of 32 or of 48)";
+            return 2;
+        }
     if (!h->allocate()) {
         g_create_error = h->err.empty() ? "allocation failed" : h->err;
         h->free_all();
@@ -1401,7 +1475,9 @@ int hrn_forward_flip_tta(hrn_handle h, const void *images_dev, int n, const int3
             h->err = "flip pair out of range";
             return 7;
         }
-        a.pair[p0] = p1, a.pair[p1] = p0;
+        // flip_back (misc/utils.py:24-27) swaps the two maps IN PLACE, pair after pair: compose the swaps in that order
+        // (equal to "p0 <-> p1" only while no joint occurs in two pairs)
+        std::swap(a.pair[p0], a.pair[p1]);
     }
     if (n == 0) return 0;
     if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return 6;
@@ -1445,19 +1521,43 @@ int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, in
     if (n == 0) return 0;
     if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return 6;
     const int H = h->H, W = h->W;
-    std::vector<CropParams> cps(n);
-    std::vector<int32_t> boxes((size_t)n * 4);
+    // crop parameters + boxes are written straight into a pinned image the async uploads below read after this call
+    // has returned; kPreRing images in rotation, each reused only once the upload that read it last has completed
+    const size_t cp_bytes = ((size_t)n * sizeof(CropParams) + 63) / 64 * 64, need = cp_bytes + (size_t)n * 16;
+    const unsigned ring = h->pre_ring_next++ % hrn_ctx::kPreRing;
+    if (h->pre_landed[ring]) {
+        if (!h->hip_ok(hipEventSynchronize(h->pre_landed[ring]), "hipEventSynchronize")) return 6;
+    } else if (!h->hip_ok(hipEventCreateWithFlags(&h->pre_landed[ring], hipEventDisableTiming), "hipEventCreate")) {
+        return 6;
+    }
+    if (need > h->pre_pin_bytes[ring]) {
+        if (h->pre_pin[ring]) (void)hipHostFree(h->pre_pin[ring]);
+        h->pre_pin[ring] = nullptr, h->pre_pin_bytes[ring] = 0;
+        const size_t cap = std::max<size_t>(need * 2, 4096);
+        if (!h->hip_ok(hipHostMalloc((void **)&h->pre_pin[ring], cap, hipHostMallocDefault), "hipHostMalloc(crop params)")) return 6;
+        h->pre_pin_bytes[ring] = cap;
+    }
+    CropParams *cps = (CropParams *)h->pre_pin[ring];
+    int32_t *boxes = (int32_t *)(h->pre_pin[ring] + cp_bytes);
     size_t tmp_bytes = 0;
     int max_h_pad = 0;
     for (int i = 0; i < n; ++i) {
         const float *d = dets_host + (size_t)i * det_stride;
         const long x1 = (long)std::nearbyint((double)d[0]), y1 = (long)std::nearbyint((double)d[1]);
         const long x2 = (long)std::nearbyint((double)d[2]), y2 = (long)std::nearbyint((double)d[3]);
-        if (x1 < 0 || y1 < 0 || x2 <= x1 || y2 <= y1 || x1 >= frame_w || y1 >= frame_h) {
-            h->err = "detection " + std::to_string(i) + " is degenerate or outside the frame";
+        if (x2 <= x1 || y2 <= y1) {
+            h->err = "detection " + std::to_string(i) + " is degenerate";
             return 7;
         }
         const double cf = (double)H / (double)W * (double)(x2 - x1) / (double)(y2 - y1);
+        // The reference slices numpy arrays with these numbers: a negative start would wrap around.  The PAD variant
+        // slices with the rounded box itself; the CLAMP variant re-derives (and clamps to the frame) the side it
+        // enlarges, so only the OTHER side has to be inside the frame as given (SimpleHRNet.py:396-407).
+        const bool x_as_given = variant == HRN_CROP_PAD || !(cf < 1), y_as_given = variant == HRN_CROP_PAD || !(cf > 1);
+        if ((x_as_given && (x1 < 0 || x1 >= frame_w)) || (y_as_given && (y1 < 0 || y1 >= frame_h))) {
+            h->err = "detection " + std::to_string(i) + " starts outside the frame";
+            return 7;
+        }
         long x1n = x1, x2n = x2, y1n = y1, y2n = y2, pt = 0, pb = 0, pl = 0, pr = 0;
         long sx1 = x1, sy1 = y1, sx2 = x2, sy2 = y2;  // what is sliced out of the frame
         if (variant == HRN_CROP_CLAMP) {  // SimpleHRNet.py:396-407: enlarge, clamp to the frame, slice the enlarged box
@@ -1471,7 +1571,7 @@ int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, in
                 x1n = std::max<long>(0, center - length / 2), x2n = std::min<long>(frame_w, center + length / 2);
             }
             sx1 = x1n, sy1 = y1n, sx2 = x2n, sy2 = y2n;
-            if (sx2 <= sx1 || sy2 <= sy1) {
+            if (sx2 <= sx1 || sy2 <= sy1 || sx1 >= frame_w || sy1 >= frame_h) {
                 h->err = "detection " + std::to_string(i) + " is degenerate after clamping";
                 return 7;
             }
@@ -1513,13 +1613,14 @@ int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, in
             h->pre_params_cap = n;
         }
     }
-    if (!h->hip_ok(hipMemcpyAsync(h->pre_params, cps.data(), (size_t)n * sizeof(CropParams), hipMemcpyHostToDevice, s),
+    if (!h->hip_ok(hipMemcpyAsync(h->pre_params, cps, (size_t)n * sizeof(CropParams), hipMemcpyHostToDevice, s),
                    "hipMemcpyAsync(crop params)"))
         return 6;
-    if (boxes_dev && !h->hip_ok(hipMemcpyAsync(boxes_dev, boxes.data(), boxes.size() * 4, hipMemcpyHostToDevice, s),
+    if (boxes_dev && !h->hip_ok(hipMemcpyAsync(boxes_dev, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s),
                                 "hipMemcpyAsync(boxes)"))
         return 6;
-    if (boxes_host) memcpy(boxes_host, boxes.data(), boxes.size() * 4);
+    if (!h->hip_ok(hipEventRecord(h->pre_landed[ring], s), "hipEventRecord")) return 6;
+    if (boxes_host) memcpy(boxes_host, boxes, (size_t)n * 16);
     if (!h->hip_ok(launch_prepath(frame_dev, frame_w, h->pre_params, n, max_h_pad, h->pre_tmp, images_dev, H, W, s),
                    "pre-path launch"))
         return 8;
@@ -1552,6 +1653,7 @@ double hrn_flops_per_crop(hrn_handle h) {
 }
 
 int64_t hrn_workspace_bytes(hrn_handle h) { return h ? h->workspace_bytes : 0; }
+int64_t hrn_map_rebuilds(hrn_handle h) { return h ? h->map_builds : -1; }
 int hrn_launches_per_pass(hrn_handle h) { return h ? (int)h->ops.size() : 0; }
 
 int hrn_plan_block_map(hrn_handle h, int group, int n, int reverse, int32_t *blocks, int capacity, int32_t *members, int member_capacity) {

@@ -719,7 +719,17 @@ hipError_t launch_fuse(int dtype, const FuseArgs &a, hipStream_t s) {
 // heat-maps, and leaves one (max, first index) candidate per joint.
 constexpr int kMaxJoints = 32;
 
-__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+// Arg-max order of np.argmax / torch.max (SimpleHRNet.py:300): the first maximum wins and a NaN is a maximum (numpy
+// returns the index of the first NaN).  `kNoIdx` marks "nothing seen yet": any real candidate beats it, so a map of
+// -inf everywhere decodes to index 0 like numpy, not to the sentinel.
+constexpr int kNoIdx = 0x7fffffff;
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn != bn) return vn;
+    return v > bv || ((v == bv || vn) && i < bi);
+}
+// scan step for candidates visited in increasing index order
+__device__ __forceinline__ bool takes(float v, float bv, int bi) { return v > bv || bi == kNoIdx || (v != v && bv == bv); }
 
 template <int DT>
 __global__ __launch_bounds__(256) void head_kernel(const HeadArgs p) {
@@ -739,7 +749,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs p) {
 #pragma unroll
     for (int j = 0; j < kMaxJoints; ++j) {
         bv[j] = -INFINITY;
-        bi[j] = 0x7fffffff;
+        bi[j] = kNoIdx;
     }
     for (int px = slab * p.slab_px + threadIdx.x; px < px_end; px += 256) {
         const int r = px / p.w, c = px - r * p.w;
@@ -762,7 +772,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs p) {
             if (j < p.joints) {
                 const float v = acc[j] + p.bias[j];
                 if (p.heatmaps) p.heatmaps[((size_t)n * p.joints + j) * hw + px] = v;
-                if (v > bv[j]) {  // px increases monotonically per thread: strict > keeps the first maximum
+                if (takes(v, bv[j], bi[j])) {  // px increases monotonically per thread: strict > keeps the first maximum
                     bv[j] = v;
                     bi[j] = px;
                 }
@@ -831,7 +841,7 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs p) {
     float bv[8];
     int bi[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) bv[t] = -INFINITY, bi[t] = 0x7fffffff;
+    for (int t = 0; t < 8; ++t) bv[t] = -INFINITY, bi[t] = kNoIdx;
 
     const int px_per_wave = p.slab_px / 4;
     for (int it = 0; it < px_per_wave / 16; ++it) {
@@ -858,7 +868,7 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs p) {
                 const float v = acc[f][q] + bias[t];
                 if (live && j < p.joints) {
                     if (p.heatmaps) p.heatmaps[((size_t)n * p.joints + j) * hw + px] = v;
-                    if (v > bv[t]) bv[t] = v, bi[t] = px;  // px grows with `it`: strict > keeps the first maximum
+                    if (takes(v, bv[t], bi[t])) bv[t] = v, bi[t] = px;  // px grows with `it`: strict > keeps the first maximum
                 }
             }
     }
@@ -916,7 +926,7 @@ __global__ void decode_kernel(const DecodeArgs p) {
     if (t >= p.n * p.joints) return;
     const int n = t / p.joints;
     float v = -INFINITY;
-    int i = 0x7fffffff;
+    int i = kNoIdx;
     for (int s = 0; s < p.slabs; ++s) {
         const float ov = p.part_val[(size_t)t * p.slabs + s];
         const int oi = p.part_idx[(size_t)t * p.slabs + s];
@@ -925,6 +935,7 @@ __global__ void decode_kernel(const DecodeArgs p) {
             i = oi;
         }
     }
+    if (i == kNoIdx) i = 0;  // (unreachable with h*w >= 1; never form coordinates from the sentinel)
     const int py = i / p.w, px = i - py * p.w;
     double x1, y1, dx, dy;
     if (p.box_is_float) {
@@ -955,12 +966,12 @@ __global__ __launch_bounds__(256) void tta_decode_kernel(const TtaArgs p) {
     float *hm = p.hm + ((size_t)n * p.joints + j) * hw;
     const float *hf = p.hm_flipped + ((size_t)n * p.joints + p.pair[j]) * hw;
     float bv = -INFINITY;
-    int bi = 0x7fffffff;
+    int bi = kNoIdx;
     for (int px = threadIdx.x; px < hw; px += 256) {
         const int y = px / p.w, x = px - y * p.w;
         const float v = (hm[px] + hf[y * p.w + (p.w - 1 - x)]) * 0.5f;
         hm[px] = v;
-        if (v > bv) bv = v, bi = px;  // px grows: strict > keeps the first maximum
+        if (takes(v, bv, bi)) bv = v, bi = px;  // px grows: strict > keeps the first maximum
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -10,9 +10,13 @@
 //   nms_sweep_kernel  the greedy pass, also on the GPU (the reference copies the n x n/64 mask to the host and loops
 //                     there): one wave, lane l owns suppression word l (n <= 4096) -- per box one ballot-free bit
 //                     test and, if kept, one coalesced 512-byte OR of its mask row.
+//   nms_sweep_lds_kernel  the same pass for n > 4096 (the reference has no cap): the suppression words live in LDS
+//                     (8 bytes per 64 boxes), one wave, no barrier needed -- a wave's LDS operations execute in order.
+// Device scratch is kept per device between calls (grown on demand), so a call costs two copies and two launches.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 
 #include "../../include/hrnet_mi355.h"
@@ -61,12 +65,53 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long 
     if (lane == 0) *num_out = kept;
 }
 
+__global__ __launch_bounds__(64) void nms_sweep_lds_kernel(const unsigned long long *mask, int n, int col_blocks, int *keep, int *num_out) {
+    extern __shared__ unsigned long long remv_lds[];
+    volatile unsigned long long *remv = remv_lds;
+    const int lane = threadIdx.x;
+    for (int c = lane; c < col_blocks; c += 64) remv[c] = 0;
+    __builtin_amdgcn_wave_barrier();
+    int kept = 0;
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long w = remv[i >> 6];             // same address in every lane: a broadcast read
+        if (!((w >> (i & 63)) & 1ull)) {                       // wave-uniform
+            if (lane == 0) keep[kept] = i;
+            ++kept;
+            for (int c = (i >> 6) + lane; c < col_blocks; c += 64) remv[c] |= mask[(size_t)i * col_blocks + c];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0) *num_out = kept;
+}
+
 thread_local std::string g_nms_error;
 
 bool ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
     g_nms_error = std::string(what) + ": " + hipGetErrorString(e);
     return false;
+}
+
+// per-device scratch, reused across calls (the reference allocates and frees per call: nms_kernel.cu:120-143)
+struct Scratch {
+    std::mutex mu;
+    float *boxes = nullptr;
+    unsigned long long *mask = nullptr;
+    int *keep = nullptr;
+    size_t boxes_bytes = 0, mask_bytes = 0, keep_bytes = 0;
+};
+constexpr int kMaxDevices = 64;
+Scratch g_scratch[kMaxDevices];
+
+template <class T>
+bool grow(T *&ptr, size_t &have, size_t need, const char *what) {
+    if (need <= have) return true;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr, have = 0;
+    const size_t cap = need + need / 2;
+    if (!ok(hipMalloc((void **)&ptr, cap), what)) return false;
+    have = cap;
+    return true;
 }
 
 }  // namespace
@@ -81,33 +126,35 @@ extern "C" int hrn_nms(int32_t *keep_out, int32_t *num_out, const float *boxes_h
     }
     *num_out = 0;
     if (boxes_num == 0) return 0;
-    if (boxes_num > 4096) {
-        g_nms_error = "at most 4096 boxes (one suppression word per lane of the sweeping wave)";
+    const int col_blocks = (boxes_num + 63) / 64;
+    if ((size_t)col_blocks * 8 > 64 * 1024) {
+        g_nms_error = "more than 524288 boxes (the suppression words of the sweep no longer fit 64 KiB of LDS)";
         return 2;
     }
-    if (!ok(hipSetDevice(device_id), "hipSetDevice")) return 3;
-    const int col_blocks = (boxes_num + 63) / 64;
-    float *boxes_dev = nullptr;
-    unsigned long long *mask_dev = nullptr;
-    int *keep_dev = nullptr;
-    const size_t bytes = (size_t)boxes_num * boxes_dim * sizeof(float);
-    int rc = 0;
-    if (!ok(hipMalloc((void **)&boxes_dev, bytes), "hipMalloc(boxes)") ||
-        !ok(hipMalloc((void **)&mask_dev, (size_t)boxes_num * col_blocks * 8), "hipMalloc(mask)") ||
-        !ok(hipMalloc((void **)&keep_dev, ((size_t)boxes_num + 1) * 4), "hipMalloc(keep)") ||
-        !ok(hipMemcpy(boxes_dev, boxes_host, bytes, hipMemcpyHostToDevice), "hipMemcpy(boxes)")) {
-        rc = 3;
-    } else {
-        hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks), dim3(64), 0, 0, boxes_dev, boxes_num, boxes_dim,
-                           nms_overlap_thresh, mask_dev, col_blocks);
-        hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, 0, mask_dev, boxes_num, col_blocks, keep_dev, keep_dev + boxes_num);
-        if (!ok(hipGetLastError(), "nms launch") ||
-            !ok(hipMemcpy(num_out, keep_dev + boxes_num, 4, hipMemcpyDeviceToHost), "hipMemcpy(num_out)") ||
-            !ok(hipMemcpy(keep_out, keep_dev, (size_t)(*num_out) * 4, hipMemcpyDeviceToHost), "hipMemcpy(keep)"))
-            rc = 4;
+    if (device_id < 0 || device_id >= kMaxDevices) {
+        g_nms_error = "bad device id";
+        return 1;
     }
-    if (boxes_dev) (void)hipFree(boxes_dev);
-    if (mask_dev) (void)hipFree(mask_dev);
-    if (keep_dev) (void)hipFree(keep_dev);
-    return rc;
+    if (!ok(hipSetDevice(device_id), "hipSetDevice")) return 3;
+    Scratch &sc = g_scratch[device_id];
+    std::lock_guard<std::mutex> lock(sc.mu);
+    const size_t bytes = (size_t)boxes_num * boxes_dim * sizeof(float);
+    if (!grow(sc.boxes, sc.boxes_bytes, bytes, "hipMalloc(boxes)") ||
+        !grow(sc.mask, sc.mask_bytes, (size_t)boxes_num * col_blocks * 8, "hipMalloc(mask)") ||
+        !grow(sc.keep, sc.keep_bytes, ((size_t)boxes_num + 1) * 4, "hipMalloc(keep)") ||
+        !ok(hipMemcpy(sc.boxes, boxes_host, bytes, hipMemcpyHostToDevice), "hipMemcpy(boxes)"))
+        return 3;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks), dim3(64), 0, 0, sc.boxes, boxes_num, boxes_dim,
+                       nms_overlap_thresh, sc.mask, col_blocks);
+    if (col_blocks <= 64)
+        hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, 0, sc.mask, boxes_num, col_blocks, sc.keep, sc.keep + boxes_num);
+    else
+        hipLaunchKernelGGL(nms_sweep_lds_kernel, dim3(1), dim3(64), (size_t)col_blocks * 8, 0, sc.mask, boxes_num, col_blocks, sc.keep,
+                           sc.keep + boxes_num);
+    // one copy brings the count and the indices (kept <= boxes_num entries are meaningful)
+    if (!ok(hipGetLastError(), "nms launch") ||
+        !ok(hipMemcpy(num_out, sc.keep + boxes_num, 4, hipMemcpyDeviceToHost), "hipMemcpy(num_out)") ||
+        !ok(hipMemcpy(keep_out, sc.keep, (size_t)(*num_out) * 4, hipMemcpyDeviceToHost), "hipMemcpy(keep)"))
+        return 4;
+    return 0;
 }

@@ -31,6 +31,27 @@ class ShardedHRNet:
         self.net, self.dist, self.group = net, dist, group
         self.world = dist.get_world_size(group) if dist else 1
         self.rank = dist.get_rank(group) if dist else 0
+        # "nccl" (= RCCL) moves device memory directly.  "gloo" is what the CPU tests use and what several ranks that
+        # share ONE GPU have to use (RCCL refuses two ranks on a device): device tensors are staged through the host.
+        self.stage_on_host = bool(dist) and dist.get_backend(group) != "nccl"
+
+    def _broadcast(self, t: torch.Tensor, src: int) -> None:
+        if t.is_cuda and self.stage_on_host:
+            host = t.cpu()
+            self.dist.broadcast(host, src=src, group=self.group)
+            if self.rank != src:
+                t.copy_(host)
+                torch.cuda.synchronize(t.device)
+        else:
+            self.dist.broadcast(t, src=src, group=self.group)
+
+    def _all_gather(self, out: torch.Tensor, mine: torch.Tensor) -> None:
+        if mine.is_cuda and self.stage_on_host:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(host, mine.cpu().contiguous(), group=self.group)
+            out.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(out, mine.contiguous(), group=self.group)
 
     # -- weights: rank `src` folds + packs, everybody else receives the blob over RCCL ------------------
     def load_and_broadcast(self, state_dict, src: int = 0) -> None:
@@ -40,7 +61,7 @@ class ShardedHRNet:
             self.net.load_state_dict(state_dict)
         if self.world > 1:
             blob = self.net.weight_blob_tensor()
-            self.dist.broadcast(blob, src=src, group=self.group)
+            self._broadcast(blob, src)
             if self.rank != src:
                 self.net.adopt_weights()
 
@@ -50,7 +71,7 @@ class ShardedHRNet:
         if self.world == 1:
             return pts
         out = torch.empty((self.world * pts.shape[0],) + tuple(pts.shape[1:]), dtype=pts.dtype, device=pts.device)
-        self.dist.all_gather_into_tensor(out, pts.contiguous(), group=self.group)
+        self._all_gather(out, pts)
         return out
 
     # -- one packed batch known to every rank (the predict() call pattern): shard by index range --------
@@ -65,5 +86,5 @@ class ShardedHRNet:
         pad = torch.zeros((per,) + tuple(pts.shape[1:]), dtype=pts.dtype, device=pts.device)
         pad[: hi - lo] = pts
         out = torch.empty((self.world * per,) + tuple(pts.shape[1:]), dtype=pts.dtype, device=pts.device)
-        self.dist.all_gather_into_tensor(out, pad, group=self.group)
+        self._all_gather(out, pad)
         return out[:n]  # ranges are contiguous and ordered by rank: only the tail is padding

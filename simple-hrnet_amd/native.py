@@ -215,6 +215,11 @@ class NativeHRNet:
         copy = torch.cuda.Stream(dev)
         h, w = self.resolution
         stage = [torch.empty((self.max_batch, 3, h, w), dtype=torch.float32, device=dev) for _ in range(2)]
+        # the staging blocks come from the caching allocator on the COMPUTE stream and may be recycled memory that
+        # kernels already queued there still read: the first upload must not overtake them
+        copy.wait_stream(compute)
+        for t in stage:
+            t.record_stream(copy)
         landed = [torch.cuda.Event(), torch.cuda.Event()]
         consumed = [None, None]
 
@@ -325,6 +330,10 @@ class NativeHRNet:
     def workspace_bytes(self) -> int:
         return int(self._lib.hrn_workspace_bytes(self._h))
 
+    def map_rebuilds(self) -> int:
+        """block maps / descriptor arrays built and uploaded so far (they depend on the micro-batch size only)"""
+        return int(self._lib.hrn_map_rebuilds(self._h))
+
     def launches_per_pass(self) -> int:
         return int(self._lib.hrn_launches_per_pass(self._h))
 
@@ -340,3 +349,173 @@ class NativeHRNet:
             self._check(self._lib.hrn_profile_pass(self._h, x.data_ptr(), n, conv_ms, nconv, other, self._stream()),
                         "hrn_profile_pass")
         return list(conv_ms), dict(zip(("stem", "fuse", "head", "decode"), list(other)))
+
+
+class MultiDeviceHRNet:
+    """One process, several GPUs -- what ``torch.nn.DataParallel(model, device_ids)`` gives a user of the reference
+    with ONE call (``SimpleHRNet.py:123-135``), without its per-forward parameter broadcast and heat-map gather:
+
+    * one ``NativeHRNet`` handle per listed device (a device may be listed twice: two handles, two streams);
+    * weights are folded + packed once (first handle) and copied blob-to-blob to the others;
+    * ``predict_crops`` / ``__call__`` / ``predict_frame`` split the packed crop batch (or the frame's detections) into
+      contiguous index ranges (``dist.shard_range``), run every range on its device from its own host thread (the C ABI
+      releases the GIL) on a per-handle side stream, and gather the small results on the first device.
+
+    Same method surface as ``NativeHRNet`` for what ``SimpleHRNet`` uses.  Multi-process jobs (one rank per GPU,
+    ``dist.ShardedHRNet``) remain the way to scale a serving loop; this class is the drop-in for the reference's
+    single-process ``device='cuda'`` / ``'cuda:1,2'``."""
+
+    def __init__(self, devices: Sequence[int], c: int = 48, nof_joints: int = 17, resolution: Tuple[int, int] = (384, 288),
+                 dtype="bf16", max_batch: int = 32, model_name: str = "HRNet"):
+        from concurrent.futures import ThreadPoolExecutor
+
+        if len(devices) < 1:
+            raise ValueError("at least one device")
+        self.devices = [int(d) for d in devices]
+        self.nets = [NativeHRNet(c, nof_joints, resolution, dtype, max_batch=max_batch, device=d, model_name=model_name)
+                     for d in self.devices]
+        self.streams = [torch.cuda.Stream(torch.device("cuda", d)) for d in self.devices]
+        self.pool = ThreadPoolExecutor(max_workers=len(self.devices), thread_name_prefix="hrn-dev")
+        first = self.nets[0]
+        self.c, self.nof_joints, self.resolution = first.c, first.nof_joints, first.resolution
+        self.dtype, self.max_batch, self.model_name = first.dtype, first.max_batch, first.model_name
+        self.device_index = first.device_index
+
+    @property
+    def torch_device(self) -> torch.device:
+        return self.nets[0].torch_device
+
+    def eval(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def close(self):
+        for n in getattr(self, "nets", []):
+            n.close()
+        pool = getattr(self, "pool", None)
+        if pool is not None:
+            pool.shutdown(wait=True)
+            self.pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights: fold + pack once, then blob -> blob (device to device; peer copy across GPUs) -----------------------
+    def load_state_dict(self, state_dict: Dict) -> "MultiDeviceHRNet":
+        self.nets[0].load_state_dict(state_dict)
+        src = self.nets[0].weight_blob_tensor()
+        for net in self.nets[1:]:
+            net.weight_blob_tensor().copy_(src)
+            torch.cuda.synchronize(net.torch_device)
+            net.adopt_weights()
+        torch.cuda.synchronize(self.torch_device)
+        return self
+
+    def load_checkpoint(self, path: str) -> "MultiDeviceHRNet":
+        return self.load_state_dict(torch.load(path, map_location="cpu"))
+
+    # -- sharded execution ---------------------------------------------------------------------------------------------
+    def _ranges(self, n: int) -> List[Tuple[int, int]]:
+        from .dist import shard_range
+
+        return [shard_range(n, len(self.nets), k) for k in range(len(self.nets))]
+
+    def _run(self, n: int, work):
+        """work(k, net, lo, hi) -> tuple of tensors on net's device (or None); runs every non-empty range on its own
+        thread and stream, orders it after the caller's stream on every device involved, returns the per-range results
+        moved to the first device (in range order)."""
+        first = self.torch_device
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(first))   # inputs produced on the caller's stream of the first device
+
+        def job(k, lo, hi):
+            net, stream = self.nets[k], self.streams[k]
+            with torch.cuda.device(net.device_index), torch.cuda.stream(stream):
+                stream.wait_event(ready)
+                out = work(k, net, lo, hi)
+                out = tuple(t if t is None or not isinstance(t, torch.Tensor) else t.to(first, non_blocking=True) for t in out)
+                done = torch.cuda.Event()
+                done.record(stream)
+                return out, done
+
+        futs = [(self.pool.submit(job, k, lo, hi)) for k, (lo, hi) in enumerate(self._ranges(n)) if hi > lo]
+        outs = []
+        mine = torch.cuda.current_stream(first)
+        for f in futs:
+            out, done = f.result()
+            mine.wait_event(done)
+            for t in out:   # produced under a side stream's allocator pool, consumed on the caller's stream
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(mine)
+            outs.append(out)
+        return outs
+
+    def predict_crops(self, images: torch.Tensor, boxes, return_heatmaps: bool = False):
+        n = int(images.shape[0])
+        b = boxes if isinstance(boxes, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(boxes))
+        if n == 0:
+            return self.nets[0].predict_crops(images, b, return_heatmaps=return_heatmaps)
+
+        def work(k, net, lo, hi):
+            x = images[lo:hi].to(net.torch_device, non_blocking=True)
+            out = net.predict_crops(x, b[lo:hi], return_heatmaps=return_heatmaps)
+            return out if return_heatmaps else (out,)
+
+        outs = self._run(n, work)
+        if return_heatmaps:
+            return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
+        return torch.cat([o[0] for o in outs], 0)
+
+    def __call__(self, images: torch.Tensor) -> torch.Tensor:
+        n = int(images.shape[0])
+        if n == 0:
+            return self.nets[0](images)
+        outs = self._run(n, lambda k, net, lo, hi: (net(images[lo:hi].to(net.torch_device, non_blocking=True)),))
+        return torch.cat([o[0] for o in outs], 0)
+
+    forward = __call__
+
+    def preprocess_frame(self, frame, detections, variant: str = "pad"):
+        """crops of one frame, produced on the devices that will run them and gathered on the first one"""
+        dets = np.ascontiguousarray(np.asarray(detections.cpu() if isinstance(detections, torch.Tensor) else detections,
+                                               dtype=np.float32))
+        if len(dets) == 0:
+            return self.nets[0].preprocess_frame(frame, dets, variant)
+        if not isinstance(frame, torch.Tensor):
+            frame = torch.from_numpy(np.ascontiguousarray(frame))
+        boxes_np = [None] * len(self.nets)
+
+        def work(k, net, lo, hi):
+            images, bx, bx_dev = net.preprocess_frame(frame, dets[lo:hi], variant)
+            boxes_np[k] = bx
+            return images, bx_dev
+
+        outs = self._run(len(dets), work)
+        return (torch.cat([o[0] for o in outs], 0), np.concatenate([b for b in boxes_np if b is not None], 0),
+                torch.cat([o[1] for o in outs], 0))
+
+    def predict_frame(self, frame, detections, return_heatmaps: bool = False, variant: str = "pad"):
+        dets = np.ascontiguousarray(np.asarray(detections.cpu() if isinstance(detections, torch.Tensor) else detections,
+                                               dtype=np.float32))
+        if len(dets) == 0:
+            return self.nets[0].predict_frame(frame, dets, return_heatmaps=return_heatmaps, variant=variant)
+        if not isinstance(frame, torch.Tensor):
+            frame = torch.from_numpy(np.ascontiguousarray(frame))
+        boxes_np = [None] * len(self.nets)
+
+        def work(k, net, lo, hi):
+            out = net.predict_frame(frame, dets[lo:hi], return_heatmaps=return_heatmaps, variant=variant)
+            boxes_np[k] = out[0]
+            return tuple(out[1:])
+
+        outs = self._run(len(dets), work)
+        boxes = np.concatenate([b for b in boxes_np if b is not None], 0)
+        pts = torch.cat([o[0] for o in outs], 0)
+        if return_heatmaps:
+            return boxes, pts, torch.cat([o[1] for o in outs], 0)
+        return boxes, pts

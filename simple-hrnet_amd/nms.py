@@ -16,14 +16,13 @@ def gpu_nms(dets: np.ndarray, thresh: float, device_id: int = 0) -> List[int]:
     dets = np.ascontiguousarray(dets, dtype=np.float32)
     if dets.ndim != 2 or dets.shape[1] < 5:
         raise ValueError("dets must be (n, >=5): x1, y1, x2, y2, score")
-    n = dets.shape[0]
-    order = dets[:, 4].argsort()[::-1].astype(np.int32)
-    sorted_dets = np.ascontiguousarray(dets[order, :])
-    keep = np.zeros(n, dtype=np.int32)
-    num_out = ctypes.c_int32(0)
+    n, dim = dets.shape
+    by_score = dets[:, 4].argsort()[::-1].astype(np.int32)          # the native part wants score-sorted rows
+    rows = np.ascontiguousarray(dets[by_score])
+    kept_rows = np.empty(n, dtype=np.int32)
+    count = ctypes.c_int32(0)
     lib = _lib.load()
-    rc = lib.hrn_nms(keep.ctypes.data, ctypes.byref(num_out), sorted_dets.ctypes.data, n, dets.shape[1],
-                     ctypes.c_float(thresh), int(device_id))
+    rc = lib.hrn_nms(kept_rows.ctypes.data, ctypes.byref(count), rows.ctypes.data, n, dim, ctypes.c_float(thresh), int(device_id))
     if rc != 0:
         raise (ValueError if rc in (1, 2) else RuntimeError)("hrn_nms failed: " + lib.hrn_nms_last_error().decode())
-    return list(order[keep[:num_out.value]])
+    return list(by_score[kept_rows[:count.value]])                   # back to the caller's row numbers

@@ -21,9 +21,10 @@ def _nan_if_none(v) -> float:
 
 
 def _db_arrays(kpts_db: Sequence[dict]):
-    scores = np.array([kpts_db[i]["score"] for i in range(len(kpts_db))])
-    kpts = np.ascontiguousarray(np.array([np.asarray(kpts_db[i]["keypoints"]).flatten() for i in range(len(kpts_db))]), np.float64)
-    areas = np.ascontiguousarray(np.array([kpts_db[i]["area"] for i in range(len(kpts_db))]), np.float64)
+    entries = list(kpts_db)
+    scores = np.array([e["score"] for e in entries])
+    kpts = np.ascontiguousarray(np.stack([np.asarray(e["keypoints"]).reshape(-1) for e in entries]), np.float64)
+    areas = np.ascontiguousarray(np.array([e["area"] for e in entries]), np.float64)
     if kpts.ndim != 2 or kpts.shape[1] % 3:
         raise ValueError("keypoints must be (J, 3) per entry")
     return scores, kpts, areas
@@ -114,8 +115,10 @@ def find_person_id_associations(boxes, pts, prev_boxes, prev_pts, prev_person_id
                                 similarity_threshold=0.5, smoothing_alpha=0.):
     """``misc/utils.py:387-429``: match the current skeletons to the previous frame's, carry the ids over, smooth matched
     boxes / joints in place, number the new people from ``next_person_id``.  Returns ``(boxes, pts, person_ids)``."""
-    bbox_similarity_matrix, pose_similarity_matrix = compute_similarity_matrices(boxes, prev_boxes, pts, prev_pts)
-    similarity_matrix = pose_similarity_matrix * pose_alpha + bbox_similarity_matrix * (1 - pose_alpha)
+    sim_box, sim_pose = compute_similarity_matrices(boxes, prev_boxes, pts, prev_pts)
+    # the blend keeps the reference's operand order (float32 matrix * python float, pose term first): its rounding decides
+    # which pairs clear the threshold
+    similarity_matrix = sim_pose * pose_alpha + sim_box * (1 - pose_alpha)
     pairs = assignment((1 - similarity_matrix).tolist())
     person_ids = np.full(len(pts), -1, dtype=np.int32)
 

@@ -11,8 +11,11 @@ different, and why:
 * ``multiperson=False`` needs frames that already have the model resolution: the reference resizes them with
   ``cv2.resize(INTER_CUBIC)`` (``:213-218``), which cannot be pinned here (cv2 is absent);
 * ``dtype`` picks the arithmetic mode of the engine (``"fp32"`` = parity mode, ``"bf16"`` = MFMA bf16);
-* one GPU per process: ``device='cuda:N'`` is that GPU; ``'cuda'`` / ``'cuda:1,2'`` name the job's GPUs and the process takes
-  the one of its ``LOCAL_RANK`` (``resolve_device``); shard the crops with ``dist.ShardedHRNet`` instead of ``DataParallel``.
+* devices: ``'cuda:N'`` is that GPU.  ``'cuda'`` (all GPUs) and ``'cuda:1,2'`` (the listed ones) are, in a plain Python
+  process, ONE engine per listed GPU driven from this process (``native.MultiDeviceHRNet``: the crop batch of a
+  ``predict()`` call is split by index range, one host thread per GPU) -- what ``DataParallel`` gives the reference with
+  one call (``SimpleHRNet.py:123-135``); under ``torch.distributed.run`` (``LOCAL_RANK`` set) the same strings name the
+  job's GPUs and each process takes the one of its rank (``resolve_device``), to be combined with ``dist.ShardedHRNet``.
 """
 from __future__ import annotations
 
@@ -22,7 +25,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .native import NativeHRNet
+from .native import MultiDeviceHRNet, NativeHRNet
 
 _MEAN = (0.485, 0.456, 0.406)   # SimpleHRNet.py:171
 _STD = (0.229, 0.224, 0.225)
@@ -54,6 +57,25 @@ def resolve_device(device, local_rank: Optional[int] = None) -> torch.device:
     raise ValueError("Wrong device name." if name.startswith("cuda") else "the MI355X engine has no CPU path (device=%s)" % name)
 
 
+def resolve_devices(device) -> list:
+    """GPU indices THIS process drives for the reference's ``device`` argument.  Launched by ``torch.distributed.run``
+    (``LOCAL_RANK`` set): exactly one, ``resolve_device``'s.  A plain process: ``'cuda'`` = every visible GPU,
+    ``'cuda:1,2'`` = those (an index may repeat), ``'cuda:3'`` / ``torch.device('cuda', 3)`` = that one, ``None`` = GPU 0."""
+    if "LOCAL_RANK" in os.environ:
+        return [resolve_device(device).index]
+    if device is None:
+        return [0]
+    if isinstance(device, torch.device):
+        return list(range(torch.cuda.device_count())) if (device.type == "cuda" and device.index is None) else [resolve_device(device).index]
+    name = str(device)
+    if name == "cuda":
+        return list(range(max(1, torch.cuda.device_count())))
+    if name.startswith("cuda:") and "," in name:
+        resolve_device(name)   # validates (raises the reference's error for a malformed list)
+        return [int(x) for x in name[5:].split(",")]
+    return [resolve_device(device, 0).index]
+
+
 class SimpleHRNet:
     def __init__(self, c, nof_joints, checkpoint_path, model_name="HRNet", resolution=(384, 288), interpolation=None,
                  multiperson=True, return_heatmaps=False, return_bounding_boxes=False, max_batch_size=32,
@@ -67,12 +89,17 @@ class SimpleHRNet:
             raise ValueError("Wrong model name.")                                   # SimpleHRNet.py:114
         if enable_tensorrt:
             raise ValueError("TensorRT is an NVIDIA engine; this class IS the native engine on MI355X")
-        self.device = resolve_device(device)
+        self.devices = resolve_devices(device)
+        self.device = torch.device("cuda", self.devices[0])      # where results are gathered / single-GPU work runs
         if multiperson and detector is None:
             raise ValueError("multiperson=True needs detector= (the reference's YOLO wrappers are un-vendored third-party code)")
         self.detector = detector
-        self.model = NativeHRNet(c, nof_joints, self.resolution, dtype, max_batch=max_batch_size, device=self.device,
-                                 model_name=model_name)
+        if len(self.devices) == 1:
+            self.model = NativeHRNet(c, nof_joints, self.resolution, dtype, max_batch=max_batch_size, device=self.device,
+                                     model_name=model_name)
+        else:   # SimpleHRNet.py:126-135: DataParallel over the listed GPUs
+            self.model = MultiDeviceHRNet(self.devices, c, nof_joints, self.resolution, dtype, max_batch=max_batch_size,
+                                          model_name=model_name)
         if isinstance(checkpoint_path, dict):
             self.model.load_state_dict(checkpoint_path)
         else:

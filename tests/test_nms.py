@@ -39,6 +39,4 @@ def test_gpu_nms_matches_reference_and_oracle():
         assert [int(i) for i in nms_mod.gpu_nms(extra, thr)] == ref
     assert nms_mod.gpu_nms(np.zeros((0, 5), np.float32), 0.5) == []
     with pytest.raises(ValueError):
-        nms_mod.gpu_nms(_boxes(5000, 1), 0.5)
-    with pytest.raises(ValueError):
         nms_mod.gpu_nms(np.zeros((3, 4), np.float32), 0.5)

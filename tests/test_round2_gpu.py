@@ -1,0 +1,353 @@
+"""Round-2 GPU tests (through the C ABI, real MI355X):
+
+* BASELINE configs[2]'s ACTUAL code path (W48 384x288, 256 crops in one micro-batch: 512/384-pixel tiles, the fused
+  BasicBlock pass, weights through LDS, LPT block order) against the CPU oracle, directly;
+* the block-map cache keyed by micro-batch size (ragged calls stop rebuilding);
+* one process / several engines (``'cuda:0,0'``) == one engine;
+* the configs[4] clip runner == ``predict_frame`` per frame;
+* the real engine's weight blob through ``ShardedHRNet.load_and_broadcast`` in a 2-rank job sharing GPU 0, and through
+  RCCL itself in a 1-rank "nccl" group;
+* NMS beyond 4096 boxes, NaN arg-max, flip pairs that share a joint, the CLAMP variant's re-clamped side, PoseResNet-101.
+"""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_pkg, state_dict_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_pkg()
+    assert torch.cuda.is_available(), "GPU tests need a GPU: the HIP path has no CPU fallback"
+    return p
+
+
+def _oracle():
+    from oracle import hrnet_torch_oracle as T
+    return T
+
+
+# --------------------------------------------------------------------------------------------- configs[2], directly
+def test_batch256_w48_384x288_path_meets_the_oracle(pkg):
+    """VERDICT r1 "What's weak" 2: the batch-256 path reached the oracle only by transitivity.  Here crops spread over
+    the batch (first / middle / last M tiles, both ends of the walk) of ONE 256-crop micro-batch-256 call are compared
+    with the oracle: fp32 engine -> identical coordinates, heat-maps within 2e-4; bf16 engine -> the error bound of
+    test_bf16_bounded_error_and_argmax, arg-max agreement wherever the oracle's margin exceeds 4x the error."""
+    T = _oracle()
+    c, h, w, n = 48, 384, 288, 256
+    pick = [0, 85, 170, 255]
+    g = torch.Generator(device="cuda").manual_seed(1234)                       # bench.py's rank-0 batch
+    crops = torch.randn((n, 3, h, w), generator=g, device="cuda", dtype=torch.float32)
+    boxes = pkg.synth_boxes(n, seed=100)
+    sd = pkg.synth.to_torch_state_dict(state_dict_np(c))
+    ref_hm, ref_pts = T.predict_crops(sd, crops[pick].cpu(), boxes[pick])
+    sigma = ref_hm.std()
+    for dtype in ("bf16", "fp32"):
+        net = pkg.NativeHRNet(c, 17, (h, w), dtype, max_batch=256, device=0).load_state_dict(state_dict_np(c))
+        assert sum(i.algo == 2 for i in net.conv_infos()) == (64 if dtype == "bf16" else 0)   # the fused pass is in play
+        hm, pts = net.predict_crops(crops, boxes, return_heatmaps=True)
+        hm, pts = hm[pick].cpu().numpy(), pts[pick].cpu().numpy()
+        err = np.abs(hm - ref_hm).max()
+        if dtype == "fp32":
+            assert err < 2e-4, err
+            np.testing.assert_array_equal(pts[..., :2], ref_pts[..., :2])
+        else:
+            assert err < 0.05 * sigma + 0.05, (err, sigma)
+            flat, rflat = hm.reshape(4, 17, -1), ref_hm.reshape(4, 17, -1)
+            am, ram = flat.argmax(-1), rflat.argmax(-1)
+            top2 = np.sort(rflat, -1)[..., -2:]
+            decided = (top2[..., 1] - top2[..., 0]) > 4 * err
+            assert (am == ram)[decided].all()
+            print("\n[batch-256 bf16] max|dH| %.4f (sigma %.2f), arg-max agree %d/%d" % (err, sigma, (am == ram).sum(), am.size))
+            np.testing.assert_array_equal(pts[..., :2], T.decode_heatmaps(hm, boxes[pick])[..., :2])
+        net.close()
+
+
+# --------------------------------------------------------------------------------------------- block-map cache
+def test_ragged_calls_stop_rebuilding_block_maps(pkg):
+    """n = 300 / 44 / 300 ... with micro-batch 256 runs passes of 256, 44 and 44 crops: two sizes.  After the first call of
+    each, nothing is rebuilt or uploaded any more (hrn_map_rebuilds), and results stay bit-identical."""
+    c, h, w = 48, 128, 96
+    net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=256, device=0).load_state_dict(state_dict_np(c))
+    crops = torch.from_numpy(pkg.synth_crops(300, h, w, seed=3)).cuda()
+    boxes = pkg.synth_boxes(300, seed=3)
+    first = net.predict_crops(crops, boxes)              # passes of 256 and 44
+    base = net.map_rebuilds()
+    assert base > 0
+    small = net.predict_crops(crops[:44], boxes[:44])    # 44 again: cached
+    assert net.map_rebuilds() == base
+    for _ in range(3):
+        again = net.predict_crops(crops, boxes)
+        assert torch.equal(again, first)
+        assert torch.equal(net.predict_crops(crops[:44], boxes[:44]), small)
+    assert net.map_rebuilds() == base
+    # four sizes are kept; a fifth evicts the least recently used one, which is rebuilt when it comes back
+    for n in (7, 100):
+        net.predict_crops(crops[:n], boxes[:n])
+    four = net.map_rebuilds()
+    for n in (256, 44, 7, 100, 256, 44):
+        net.predict_crops(crops[:n], boxes[:n])
+    assert net.map_rebuilds() == four
+    net.predict_crops(crops[:13], boxes[:13])
+    assert net.map_rebuilds() > four
+    assert torch.equal(net.predict_crops(crops, boxes), first)
+    net.close()
+
+
+# --------------------------------------------------------------------------------------------- one process, several engines
+def test_one_process_several_engines_equals_one_engine(pkg, tmp_path):
+    """SimpleHRNet(device='cuda:0,0'): two handles on the one GPU of this box, the crop batch split by index range, one
+    host thread and one stream per handle -- the same joints, boxes and heat-maps as a single engine."""
+    from test_simple_hrnet import TableDetector
+    from test_prepath import DETS_SINGLE, _frame
+
+    c, res = 32, (128, 96)
+    sd = state_dict_np(c, 0)
+    frame = _frame(360, 480, 9)
+    dets = np.asarray([[40.2, 30.7, 200.1, 330.3], [250.5, 100.5, 460.4, 200.6], [10.0, 20.0, 100.0, 300.0],
+                       [300.0, 5.0, 470.0, 350.0], [120.0, 60.0, 220.0, 340.0]], np.float32)
+    kw = dict(resolution=res, multiperson=True, return_heatmaps=True, return_bounding_boxes=True, max_batch_size=2,
+              detector=TableDetector({0: dets, 1: dets[:2], 2: None}), dtype="bf16")
+    one = pkg.SimpleHRNet(c, 17, sd, device="cuda:0", **kw)
+    two = pkg.SimpleHRNet(c, 17, sd, device="cuda:0,0", **kw)
+    assert type(two.model).__name__ == "MultiDeviceHRNet" and len(two.model.nets) == 2
+    for _ in range(2):
+        a, b = one.predict(frame), two.predict(frame)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    stack = np.stack([frame, frame[::-1].copy(), frame])
+    a, b = one.predict(stack), two.predict(stack)
+    for xs, ys in zip(a, b):
+        for x, y in zip(xs, ys):
+            np.testing.assert_array_equal(x, y)
+    # the engine level: 11 crops over two handles, heat-maps and the level-1 seam
+    crops = torch.from_numpy(pkg.synth_crops(11, *res, seed=5)).cuda()
+    boxes = pkg.synth_boxes(11, seed=5)
+    hm1, p1 = one.model.predict_crops(crops, boxes, return_heatmaps=True)
+    hm2, p2 = two.model.predict_crops(crops, boxes, return_heatmaps=True)
+    assert torch.equal(hm1, hm2) and torch.equal(p1, p2) and torch.equal(two.model(crops), hm1)
+    assert torch.equal(two.model.predict_crops(crops.cpu(), boxes), p1)          # host-resident crops: each engine uploads its shard
+    assert tuple(two.model.predict_crops(crops[:0], boxes[:0]).shape) == (0, 17, 3)
+    two.model.close(), one.model.close()
+
+
+# --------------------------------------------------------------------------------------------- configs[4]
+def test_clip_runner_equals_predict_frame(pkg):
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    c, res = 32, (128, 96)
+    net = pkg.NativeHRNet(c, 17, res, "bf16", max_batch=32, device=0).load_state_dict(state_dict_np(c, 1))
+    clip, dets = bench.make_clip(seed=3, frames=5, people=4, hf=270, wf=480)
+    clip_host = torch.from_numpy(clip).pin_memory()
+    want = np.stack([net.predict_frame(clip[f], dets[f])[1].cpu().numpy() for f in range(len(clip))])
+    for mode in ("per_frame", "per_frame_sync"):
+        got, el = bench.run_clip(net, clip_host, dets, mode)
+        np.testing.assert_array_equal(got, want)
+        assert el > 0
+    # the stack form uses the batch path's enlarge-and-clamp boxes (SimpleHRNet.py:383-412), all crops in one batch
+    got, _ = bench.run_clip(net, clip_host, dets, "stacked")
+    crops, boxes = zip(*[net.preprocess_frame(clip[f], dets[f], "clamp")[::2] for f in range(len(clip))])
+    want_s = net.predict_crops(torch.cat(crops), torch.cat(boxes)).cpu().numpy().reshape(got.shape)
+    np.testing.assert_array_equal(got, want_s)
+    # two "ranks" deal the frames round-robin: together they cover the clip
+    a, _ = bench.run_clip(net, clip_host, dets, "per_frame", rank=0, world=2)
+    b, _ = bench.run_clip(net, clip_host, dets, "per_frame", rank=1, world=2)
+    np.testing.assert_array_equal(a + b, want)
+    net.close()
+
+
+# --------------------------------------------------------------------------------------------- multi-rank weight path
+def _rank_body(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    from conftest import load_pkg as lp, state_dict_np as sdn
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # RCCL refuses two ranks on one GPU: gloo, device tensors staged
+    try:
+        pkg = lp()
+        sh = lp("dist")
+        c, h, w, n = 32, 64, 64, 7
+        net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=4, device=0)
+        eng = sh.ShardedHRNet(net, dist)
+        assert eng.stage_on_host
+        eng.load_and_broadcast(sdn(c, 0) if rank == 0 else None, src=0)      # rank 1 never sees the state_dict
+        crops = torch.from_numpy(pkg.synth_crops(n, h, w, seed=6)).cuda()
+        boxes = pkg.synth_boxes(n, seed=6)
+        pts = eng.predict_crops_sharded(crops, boxes)                          # ragged shards 4 + 3
+        lo, hi = sh.shard_range(6, world, rank)
+        pts2 = eng.predict_crops_local_then_gather(crops[lo:hi], boxes[lo:hi])
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), pts=pts.cpu().numpy(), pts2=pts2.cpu().numpy(),
+                 blob=net.read_blob(0, min(net.weight_blob_bytes(), 1 << 20)))
+        net.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_gpu0_real_blob_broadcast(pkg, tmp_path):
+    """The REAL engine's packed blob through ShardedHRNet.load_and_broadcast and the sharded predict, two processes on
+    GPU 0 (gloo: RCCL needs one GPU per rank), against a single engine loaded the ordinary way."""
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rank_body, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    c, h, w, n = 32, 64, 64, 7
+    net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=4, device=0).load_state_dict(state_dict_np(c, 0))
+    crops = torch.from_numpy(pkg.synth_crops(n, h, w, seed=6)).cuda()
+    boxes = pkg.synth_boxes(n, seed=6)
+    want = net.predict_crops(crops, boxes).cpu().numpy()
+    blob = net.read_blob(0, min(net.weight_blob_bytes(), 1 << 20))
+    for r in range(2):
+        g = np.load(os.path.join(tmp_path, "rank%d.npz" % r))
+        np.testing.assert_array_equal(g["blob"], blob)
+        np.testing.assert_array_equal(g["pts"], want)
+        np.testing.assert_array_equal(g["pts2"], want[:6])
+    net.close()
+
+
+def _nccl_body(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    from conftest import load_pkg as lp, state_dict_np as sdn
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        pkg = lp()
+        net = pkg.NativeHRNet(32, 17, (64, 64), "bf16", max_batch=4, device=0).load_state_dict(sdn(32, 0))
+        blob = net.weight_blob_tensor()                       # zero-copy view of the handle's device blob
+        before = blob.clone()
+        dist.broadcast(blob, src=0)                           # RCCL on the blob itself
+        pts = net.predict_crops(torch.from_numpy(pkg.synth_crops(3, 64, 64, seed=1)).cuda(), pkg.synth_boxes(3, seed=1))
+        out = torch.empty((world * 3, 17, 3), dtype=pts.dtype, device=pts.device)
+        dist.all_gather_into_tensor(out, pts.contiguous())    # the per-step collective: 204 B / crop
+        torch.cuda.synchronize()
+        ok = bool(torch.equal(blob, before) and torch.equal(out, pts))
+        open(os.path.join(out_dir, "nccl_ok"), "w").write("1" if ok else "0")
+        net.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_accepts_the_blob_view_and_the_joint_gather(pkg, tmp_path):
+    """A 1-rank "nccl" group on this box's GPU: RCCL initialises, broadcasts the zero-copy blob tensor and all-gathers
+    the joints -- the two collectives of bench.py --gpus N -- without touching a second GPU."""
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_nccl_body, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert open(os.path.join(tmp_path, "nccl_ok")).read() == "1"
+
+
+# --------------------------------------------------------------------------------------------- small contract fixes
+def test_nms_beyond_4096_boxes_matches_the_reference_function(pkg):
+    from oracle import nms_oracle
+    from test_nms import _boxes
+
+    nms_mod = load_pkg("nms")
+    for n, thr, seed in [(4097, 0.5, 21), (6000, 0.4, 22)]:
+        dets = _boxes(n, seed)
+        assert [int(i) for i in nms_mod.gpu_nms(dets, thr)] == nms_oracle.nms(dets, thr)
+    small = _boxes(100, 23)                                   # the scratch of the big call is reused by a small one
+    assert [int(i) for i in nms_mod.gpu_nms(small, 0.5)] == nms_oracle.nms(small, 0.5)
+
+
+def test_nan_and_minus_inf_heatmaps_decode_like_numpy(pkg):
+    """np.argmax treats NaN as the maximum (the first NaN wins) and returns 0 for a map of -inf: such maps must decode to
+    index 0 = the box origin, never to coordinates formed from an 'unset' sentinel.  The maps are produced by
+    the real head: final_layer.bias = NaN for joint 3, -inf for joint 5."""
+    T = _oracle()
+    c, h, w = 32, 64, 64
+    sd = {k: np.array(v, copy=True) for k, v in state_dict_np(c).items()}
+    sd["final_layer.bias"][3] = np.nan
+    sd["final_layer.bias"][5] = -np.inf
+    crops = torch.from_numpy(pkg.synth_crops(2, h, w, seed=2)).cuda()
+    boxes = pkg.synth_boxes(2, seed=2)
+    for dtype in ("fp32", "bf16"):
+        net = pkg.NativeHRNet(c, 17, (h, w), dtype, max_batch=2, device=0).load_state_dict(sd)
+        hm, pts = net.predict_crops(crops, boxes, return_heatmaps=True)
+        only_pts = net.predict_crops(crops, boxes)
+        hm, pts = hm.cpu().numpy(), pts.cpu().numpy()
+        assert np.isnan(hm[:, 3]).all() and np.isneginf(hm[:, 5]).all() and np.isfinite(np.delete(hm, (3, 5), 1)).all()
+        ref = T.decode_heatmaps(hm, boxes)
+        np.testing.assert_array_equal(pts[..., :2], ref[..., :2])
+        np.testing.assert_array_equal(only_pts.cpu().numpy()[..., :2], ref[..., :2])
+        for j in (3, 5):      # index 0 -> (y1, x1)
+            np.testing.assert_array_equal(pts[:, j, 0], boxes[:, 1].astype(np.float32))
+            np.testing.assert_array_equal(pts[:, j, 1], boxes[:, 0].astype(np.float32))
+        assert np.isnan(pts[:, 3, 2]).all() and np.isneginf(pts[:, 5, 2]).all()
+        net.close()
+
+
+def test_flip_pairs_that_share_a_joint_compose_like_flip_back(pkg):
+    """flip_back swaps in place, pair after pair (misc/utils.py:24-27): (1,2),(2,3) is a 3-cycle, not two swaps."""
+    T = _oracle()
+    c, h, w = 32, 64, 64
+    sd_np = state_dict_np(c, 2)
+    crops = pkg.synth_crops(2, h, w, seed=8)
+    pairs = [(1, 2), (2, 3), (5, 6), (5, 6), (0, 16)]
+    ref = T.flip_tta_heatmaps(pkg.synth.to_torch_state_dict(sd_np), torch.from_numpy(crops), pairs).numpy()
+    net = pkg.NativeHRNet(c, 17, (h, w), "fp32", max_batch=2, device=0).load_state_dict(sd_np)
+    hm = net.predict_flip_tta(torch.from_numpy(crops).cuda(), pairs)[0].cpu().numpy()
+    np.testing.assert_allclose(hm, ref, rtol=0, atol=2e-4)
+    net.close()
+
+
+def test_clamp_variant_accepts_what_the_reference_reclamps(pkg):
+    """SimpleHRNet.py:396-407 re-derives the enlarged side with max(0, .) / min(size, .): a box that starts above / left
+    of the frame on THAT side is valid there; on the other side, and in the pad variant, it is refused."""
+    from oracle import prepath_oracle as P
+    from test_prepath import _frame
+
+    res, hf, wf = (128, 96), 240, 320
+    frame = _frame(hf, wf, 4)
+    net = pkg.NativeHRNet(32, 17, res, "fp32", max_batch=4, device=0)
+    ok = np.asarray([[30.0, -20.0, 200.0, 60.0],      # wide box: cf > 1, y re-clamped -> y1 < 0 is fine
+                     [-15.0, 20.0, 25.0, 200.0],      # tall box: cf < 1, x re-clamped -> x1 < 0 is fine
+                     [10.0, 10.0, 300.0, 230.0]], np.float32)
+    images, boxes, _ = net.preprocess_frame(frame, ok, "clamp")
+    ref_images, ref_boxes = P.prepath_clamped(frame, ok, *res)
+    np.testing.assert_array_equal(boxes, ref_boxes)
+    np.testing.assert_array_equal(images.cpu().numpy(), ref_images)
+    for bad in ([[-15.0, 20.0, 200.0, 60.0]], [[30.0, -20.0, 60.0, 200.0]]):      # the side that is sliced as given
+        with pytest.raises((ValueError, RuntimeError)):
+            net.preprocess_frame(frame, np.asarray(bad, np.float32), "clamp")
+    with pytest.raises((ValueError, RuntimeError)):
+        net.preprocess_frame(frame, ok[:1], "pad")
+    net.close()
+
+
+def test_poseresnet101_on_hardware(pkg):
+    """models_/poseresnet.py:6-12: size 101 had only been plan-tested.  One oracle seed, fp32 exact coordinates + bf16 bound."""
+    T = _oracle()
+    size, h, w, n = 101, 128, 96, 2
+    sd = pkg.synth_state_dict(size, 17, 3, model="PoseResNet")
+    crops = pkg.synth_crops(n, h, w, seed=13)
+    boxes = pkg.synth_boxes(n, seed=13)
+    with torch.no_grad():
+        ref = T.poseresnet_forward(pkg.synth.to_torch_state_dict(sd), torch.from_numpy(crops), size).numpy()
+    for dtype in ("fp32", "bf16"):
+        net = pkg.NativeHRNet(size, 17, (h, w), dtype, max_batch=2, device=0, model_name="PoseResNet").load_state_dict(sd)
+        hm, pts = net.predict_crops(torch.from_numpy(crops).cuda(), boxes, return_heatmaps=True)
+        hm, pts = hm.cpu().numpy(), pts.cpu().numpy()
+        if dtype == "fp32":
+            np.testing.assert_allclose(hm, ref, rtol=0, atol=5e-5)
+            np.testing.assert_array_equal(pts[..., :2], T.decode_heatmaps(ref, boxes)[..., :2])
+        else:
+            assert np.abs(hm - ref).max() < 0.1 * ref.std() + 0.004
+        net.close()
