@@ -50,7 +50,7 @@ typedef struct {
     int32_t in_h, in_w, out_h, out_w;
     int32_t kpad;         /* K = ksize*ksize*cin rounded up to the MFMA K-chunk                 */
     int32_t nr;           /* 16-wide cout fragments per group (packing parameter)              */
-    int32_t algo;         /* 0 generic MFMA kernel, 1 pipelined LDS-staged 3x3 stride-1 kernel, 2 = 1 as half of a fused BasicBlock (HRN_BBF=1) */
+    int32_t algo;         /* 0 generic MFMA kernel, 1 pipelined LDS-staged 3x3 stride-1 kernel, 2 = 1 as half of a fused BasicBlock (HRN_BBF=1), 3 = the 96-cout form of 1 (ks 32, nr 6) */
     int32_t ks;           /* algo 1: input channels per LDS slice (k = tap*ks + ci inside one)  */
     int64_t w_offset;     /* byte offset of the packed weights in the blob                     */
     int64_t w_bytes;

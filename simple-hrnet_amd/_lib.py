@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libhrnet_mi355.so")
 SOURCES = ["kernels.hip", "conv3x3_lds.hip", "bottleneck_chain.hip", "prepath.hip", "nms.hip", "postproc.cpp", "hrnet_mi355.cpp"]
-HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(INCLUDE, "hrnet_mi355.h")]
+HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv3x3_n96.inc"), os.path.join(INCLUDE, "hrnet_mi355.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
 

@@ -819,6 +819,8 @@ __device__ __forceinline__ void bbf_run(const Conv3Problem &p, const int mt0, co
 #endif
 }
 
+#include "conv3x3_n96.inc"
+
 template <int KS, int NRB>
 __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem *__restrict__ probs,
                                                              const int2 *__restrict__ blockmap, const int nb) {
@@ -834,6 +836,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem 
     if constexpr (KS == 48 && NRB == 3) {
         if (bm.y & (1 << 29)) {  // a fused BasicBlock (bbf_run): 512-pixel tiles, both convolutions
             bbf_run(p, mt0, tiles, nb, smem);
+            return;
+        }
+        if (p.n96) {  // 96 couts per block, 32-channel slices (conv3x3_n96.inc)
+            if (bm.y >> 30)
+                c3n_run<1>(p, nt, mt0, tiles, nb, smem);
+            else if (p.bm == 512)
+                c3n_run<4>(p, nt, mt0, tiles, nb, smem);
+            else
+                c3n_run<3>(p, nt, mt0, tiles, nb, smem);
             return;
         }
     }
@@ -869,7 +880,8 @@ template <int KS, int NRB>
 static hipError_t launch_c3(const Conv3Problem *probs_dev, const int2 *blockmap_dev, int nblocks, int nb, hipStream_t s) {
     using CFG = C3Cfg<KS, NRB>;
     // the <48, 3> launches may carry fused BasicBlocks (bbf_run), which lay LDS out differently and use all of it
-    constexpr int LDS = (KS == 48 && NRB == 3 && BBF_LDS > CFG::LDS) ? BBF_LDS : CFG::LDS;
+    constexpr int LDS = (KS == 48 && NRB == 3) ? (BBF_LDS > N96_LDS ? BBF_LDS : N96_LDS) : CFG::LDS;
+    static_assert(LDS >= CFG::LDS, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)conv3x3_lds_kernel<KS, NRB>,
@@ -881,10 +893,13 @@ static hipError_t launch_c3(const Conv3Problem *probs_dev, const int2 *blockmap_
     return hipGetLastError();
 }
 
+int conv3x3_n96_ch64() { return N96_CH64; }
+
 int conv3x3_lds_bbf_ok(int wp) { return (512 + 4 * (wp + 1)) * 6 <= BBF_XY / 16; }
 
 // pixels per M tile for a (KS, wp) pair: 512, or 384 when two 512-row slabs (+ halo) would not fit in LDS; 0 = unsupported
 int conv3x3_lds_bm(int ks, int nrb, int wp) {
+    if (ks == 32 && nrb == 6) return 512 + 2 * wp + 2 <= N96_MAXROWS ? 512 : 384 + 2 * wp + 2 <= N96_MAXROWS ? 384 : 0;
     const int maxrows = ks == 48 ? C3Cfg<48, 3>::MAXROWS : C3Cfg<32, 4>::MAXROWS;
     if (nrb != 4 && 512 + 2 * wp + 2 <= maxrows) return 512;
     if (384 + 2 * wp + 2 <= maxrows) return 384;
@@ -895,7 +910,7 @@ hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockma
                               int nrb, hipStream_t s) {
     if (nblocks <= 0) return hipSuccess;
     const int2 *bm = (const int2 *)blockmap_dev;
-    if (ks == 48 && nrb == 3) return launch_c3<48, 3>(probs_dev, bm, nblocks, nb, s);
+    if ((ks == 48 && nrb == 3) || (ks == 32 && nrb == 6)) return launch_c3<48, 3>(probs_dev, bm, nblocks, nb, s);
     if (ks == 32 && nrb == 4) return launch_c3<32, 4>(probs_dev, bm, nblocks, nb, s);
     if (ks == 32 && nrb == 3) return launch_c3<32, 3>(probs_dev, bm, nblocks, nb, s);
     if (ks == 32 && nrb == 2) return launch_c3<32, 2>(probs_dev, bm, nblocks, nb, s);

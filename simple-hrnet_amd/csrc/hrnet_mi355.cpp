@@ -47,6 +47,7 @@ struct ConvOp {
     int algo = 0;          // 0 = generic kernel (kernels.hip), 1 = pipelined LDS-staged 3x3 stride 1 (conv3x3_lds.hip)
     int up = 0;            // 1 + 2a + b: phase (a, b) of a ConvTranspose2d(4, s2, p1) as a 3x3 conv on the input grid
     int ks = 0, slices = 0, ntiles = 0, nch = 0;
+    bool n96 = false;      // 96-cout form of the LDS-staged kernel (conv3x3_n96.inc): ks = 32, nr = 6, same launch family as (48, 3)
     int fuse_with = -1;    // conv1 of a BasicBlock that can also compute this conv2 (conv3x3_lds.hip: bbf_run)
     bool fused_away = false;  // conv2 of such a block: skipped in its own launch whenever conv1's launch ran fused
     int64_t w_off = 0, w_bytes = 0, b_off = 0;
@@ -168,6 +169,7 @@ struct hrn_ctx {
     // 1: convolutions that read the same tensor share one cout-tile width so that they can share a launch (and L2)
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
+    bool disable_n96 = getenv("HRN_DISABLE_N96") != nullptr;   // 96-cout form off: those convolutions take the (48, 3) form
     bool disable_stem_mfma = getenv("HRN_DISABLE_STEM_MFMA") != nullptr;
     bool disable_head_mfma = getenv("HRN_DISABLE_HEAD_MFMA") != nullptr;
     bool direct_nr6 = getenv("HRN_DIRECT_NR6") ? atoi(getenv("HRN_DIRECT_NR6")) != 0 : true;
@@ -253,7 +255,12 @@ struct hrn_ctx {
         // 64-, 48- or 32-cout tiles for everything else whose channel counts are multiples of 32
         int lds_ks = 0, lds_nrb = 0;
         if (dtype == HRN_BF16 && k == 3 && stride == 1 && !disable_lds && !up) {
-            if (op.cin % 48 == 0 && cout % 48 == 0)
+            // widths that are multiples of 96 (the 96 / 192 / 384-channel branches of W48): 96 couts per block, 32-channel slices.
+            // At EVERY batch size (its K order differs from the other forms'); its address arithmetic is 32-bit: tensors < 4 GB.
+            const int64_t out_bytes = ((int64_t)max_batch * (oh + 1) * (ow + 1) + 2 * (ow + 2) + 512) * std::max(op.cin, cout) * 2;
+            if (!disable_n96 && op.cin % 32 == 0 && cout % 96 == 0 && conv3x3_lds_bm(32, 6, ow + 1) > 0 && out_bytes < (int64_t(1) << 32))
+                lds_ks = 32, lds_nrb = 6, op.n96 = true;
+            else if (op.cin % 48 == 0 && cout % 48 == 0)
                 lds_ks = 48, lds_nrb = 3;
             else if (op.cin % 32 == 0 && !disable_lds32)
                 lds_ks = 32, lds_nrb = cout % 64 == 0 ? 4 : cout % 48 == 0 ? 3 : cout % 32 == 0 ? 2 : 0;
@@ -268,6 +275,9 @@ struct hrn_ctx {
         if (emit) emit_convs({(int)convs.size() - 1});
         return op.out_t;
     }
+
+    // the (48, 3) and the (32, 6) form live in one kernel (conv3x3_lds_kernel<48, 3>) and share launches
+    static int c3_family(const ConvOp &cv) { return ((cv.ks == 48 && cv.nr == 3) || cv.n96) ? 0 : cv.ks * 16 + cv.nr; }
 
     // emit a set of mutually independent convolutions: one grouped launch when all of them run on the
     // LDS-staged kernel, individual launches otherwise
@@ -306,7 +316,7 @@ struct hrn_ctx {
             bool placed = false;
             if (!disable_group)
                 for (auto &set : sets)
-                    if (convs[set[0]].ks == convs[i].ks && convs[set[0]].nr == convs[i].nr) {
+                    if (c3_family(convs[set[0]]) == c3_family(convs[i])) {
                         set.push_back(i);
                         placed = true;
                         break;
@@ -621,6 +631,8 @@ struct hrn_ctx {
 
     // every block walks ~`half_stages_per_block` half-slices so that blocks of all branches last alike
     int conv3_tiles_per_block(const ConvOp &cv) const {
+        // (96-cout form: three stages of 18 MR MFMAs per slice, each about 0.86 of a (48, 3) half-stage)
+        if (cv.n96) return std::max(1, (half_stages_per_block * 7) / (6 * 3 * cv.slices));
         const int t = half_stages_per_block / ((cv.ks == 48 ? 2 : 1) * cv.slices);
         return t < 1 ? 1 : t;
     }
@@ -713,7 +725,10 @@ struct hrn_ctx {
                             if (tiles > tpb) tiles = tpb;
                             double key = (i + 0.5) / total;  // proportional interleave of the problems
                             if (block_order == 1)            // longest-processing-time first (estimated block cost)
-                                key = -(double)tiles * (fused ? 28000.0 : cv.slices * 2.0 * (bm == 512 ? 4300.0 : 3500.0) + (bm == 512 ? 5000.0 : 3000.0)) + 1e-3 * key;
+                                key = -(double)tiles * (fused    ? 28000.0
+                                                        : cv.n96 ? cv.slices * 3.0 * (bm == 512 ? 3900.0 : 3000.0) + (bm == 512 ? 7000.0 : 5000.0)
+                                                                 : cv.slices * 2.0 * (bm == 512 ? 4300.0 : 3500.0) + (bm == 512 ? 5000.0 : 3000.0)) +
+                                      1e-3 * key;
                             int mt0 = first + mg * tpb;
                             // every other launch walks the tensors backwards: a launch starts on what its producer
                             // wrote last, i.e. on the part most likely still in the Infinity Cache
@@ -876,6 +891,7 @@ struct hrn_ctx {
                 q.cin = cv.cin, q.cout = cv.cout, q.h = to.h, q.wd = to.w, q.wp = to.wp, q.hpwp = to.hpwp;
                 q.relu = cv.relu, q.slices = cv.slices, q.ntiles = cv.ntiles;
                 q.w2 = nullptr, q.bias2 = nullptr;
+                q.n96 = cv.n96 ? 1 : 0;
                 q.tiles_per_block = conv3_tiles_per_block(cv);
                 q.bm = conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
                 fast_div(to.hpwp, &q.magic_hpwp, &q.shift_hpwp);
@@ -1138,7 +1154,9 @@ struct hrn_ctx {
                     for (int j = 0; j < NRB; ++j)
                         for (int lane = 0; lane < 64; ++lane) {
                             const int li = lane & 15, g = lane >> 4;
-                            const int co = t * 16 * NRB + (li >> 2) * 4 * NRB + j * 4 + (li & 3);
+                            // (96-cout form: conv3x3_n96.inc N96_CH64 -- a lane's channels are 8 contiguous ones per 32-channel group)
+                            const int co = (cv.n96 && conv3x3_n96_ch64()) ? t * 96 + (j >> 1) * 32 + (li >> 2) * 8 + (j & 1) * 4 + (li & 3)
+                                                                          : t * 16 * NRB + (li >> 2) * 4 * NRB + j * 4 + (li & 3);
                             uint16_t *d = blk + ((size_t)(c * NRB + j) * 64 + lane) * 8;
                             for (int e = 0; e < 8; ++e) {
                                 const int kl = 32 * c + 8 * g + e;
@@ -1638,7 +1656,7 @@ int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out) {
     out->has_residual = cv.res_t >= 0;
     out->in_h = h->tensors[cv.in_t].h, out->in_w = h->tensors[cv.in_t].w;
     out->out_h = h->tensors[cv.out_t].h, out->out_w = h->tensors[cv.out_t].w;
-    out->kpad = cv.kpad, out->nr = cv.nr, out->algo = cv.fuse_with >= 0 || cv.fused_away ? 2 : cv.algo, out->ks = cv.ks;
+    out->kpad = cv.kpad, out->nr = cv.nr, out->algo = cv.fuse_with >= 0 || cv.fused_away ? 2 : cv.n96 ? 3 : cv.algo, out->ks = cv.ks;
     out->w_offset = cv.w_off, out->w_bytes = cv.w_bytes, out->b_offset = cv.b_off;
     out->flops = cv.flops;
     return 0;

@@ -55,9 +55,12 @@ struct Conv3Problem {
     // output and `in` doubles as the residual
     const void *w2;
     const float *bias2;
+    // 96-cout form (conv3x3_n96.inc): KS = 32, ntiles = cout / 96, bm = 512 or 384
+    int n96;
 };
+int conv3x3_n96_ch64();           // output-channel permutation of the 96-cout form's weight image (conv3x3_n96.inc)
 int conv3x3_lds_bbf_ok(int wp);  // the fused BasicBlock kernel fits this row pitch
-int conv3x3_lds_bm(int ks, int nrb, int wp);
+int conv3x3_lds_bm(int ks, int nrb, int wp);  // (32, 6) = the 96-cout form
 
 // layer1: conv3 (+shortcut, ReLU) of one Bottleneck and conv1 (+ReLU) of the next in one pass (bottleneck_chain.hip)
 struct ChainArgs {

@@ -79,6 +79,8 @@ def _unpack_lds(net, info):
                     for lane in range(64):
                         li, g = lane & 15, lane >> 4
                         co = t * 16 * nrb + (li >> 2) * 4 * nrb + j * 4 + (li & 3)
+                        if info.algo == 3:   # the 96-cout form: 8 contiguous channels per lane in each 32-channel group
+                            co = t * 96 + (j >> 1) * 32 + (li >> 2) * 8 + (j & 1) * 4 + (li & 3)
                         for e in range(8):
                             kl = 32 * c + 8 * g + e
                             v = vals[t, s, c, j, lane, e]
@@ -92,7 +94,7 @@ def _unpack_lds(net, info):
 
 def _unpack(net, info, dtype):
     """inverse of the documented fragment-major layout"""
-    if info.algo == 1:
+    if info.algo in (1, 3):   # 3 = the 96-cout form: same image with ks = 32, nr = 6
         return _unpack_lds(net, info)
     kc, vec = (32, 8) if dtype == "bf16" else (16, 4)
     raw = net.read_blob(info.w_offset, info.w_bytes)

@@ -24,6 +24,19 @@ for _ in range(3):
     net(x)
 torch.cuda.synchronize()
 lib.hrn_debug_c3_timing(buf.ctypes.data, NB)
+n96 = buf[(buf[:, 0, 6] >= 90) & (buf[:, 0, 6] < 100)]   # 96-cout form (conv3x3_n96.inc): per-stage / per-tile phases
+if len(n96):
+    for S in sorted(set(n96[:, 0, 5] // np.maximum(1, n96[:, 0, 7] >> 48) // 3)):
+        sel = n96[(n96[:, 0, 5] // np.maximum(1, n96[:, 0, 7] >> 48) // 3) == S]
+        st, nt = sel[:, :, 5].astype(float), (sel[:, :, 7] >> 48).astype(float)
+        erest = (sel[:, :, 7] & ((1 << 48) - 1)).astype(float)
+        print("96-cout form, S=%d (cin %d): %d blocks, %.1f stages, %.1f tiles per block, total/block %.0f ticks (ideal MFMA per stage and SIMD: %d)" % (
+            S, 32 * S, len(sel), st[:, 0].mean(), nt[:, 0].mean(), sel[:, 0, 4].mean(), 2 * 18 * (int(sel[0, 0, 6]) - 90) * 16))
+        for w in range(8):
+            print("    wave %d: per stage: entry wait %.0f  plan/residual issue %.0f  chunks %.0f | per tile: residual wait %.0f  epilogue rest %.0f" % (
+                w, (sel[:, w, 0] / st[:, w]).mean(), (sel[:, w, 1] / st[:, w]).mean(), (sel[:, w, 2] / st[:, w]).mean(),
+                (sel[:, w, 3] / nt[:, w]).mean(), (erest[:, w] / nt[:, w]).mean()))
+    buf[(buf[:, 0, 6] >= 90) & (buf[:, 0, 6] < 100)] = 0
 fz = buf[buf[:, 0, 6] >= 100]   # fused BasicBlock blocks (bbf_run) record their own phases
 if len(fz):
     nt = fz[:, 0, 5].astype(float)
