@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("HRN_MAX_BATCH", "256")),
                     help="crops per internal pass (workspace size)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("HRN_LANES", "1")),
+                    help="engines per GPU, each running batch/lanes crops per step on its own stream (1 = one engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline AND parity (both need the CPU oracle)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--no-roofline", action="store_true")
@@ -184,7 +186,7 @@ def source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "simple-hrnet_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".cpp", ".h")):
+        if name.endswith((".hip", ".cpp", ".h", ".inc")):
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
@@ -509,8 +511,23 @@ def main():
     boxes_np = pkg.synth_boxes(a.batch, seed=100 + rank)
     boxes = torch.from_numpy(boxes_np).to(dev)
 
+    # the timed path: `lanes` engines on this rank's GPU, each on its own stream with batch / lanes crops per step -- the
+    # launches of one lane fill the drain and the tail of the other's (same kernels, same joints; native.MultiDeviceHRNet)
+    lanes_eng = None
+    if a.lanes > 1 and a.batch >= 2 * a.lanes:
+        native = importlib.import_module("simple-hrnet_amd.native")
+        lanes_eng = native.MultiDeviceHRNet([local] * a.lanes, a.c, 17, (a.height, a.width), a.dtype,
+                                            max_batch=min(a.max_batch, -(-a.batch // a.lanes)), model_name=a.model_name).adopt_from(net)
+
     def step():
-        return eng.predict_crops_local_then_gather(images, boxes)
+        if lanes_eng is None:
+            return eng.predict_crops_local_then_gather(images, boxes)
+        pts = lanes_eng.predict_crops(images, boxes)
+        if world == 1:
+            return pts
+        out = torch.empty((world * pts.shape[0],) + tuple(pts.shape[1:]), dtype=pts.dtype, device=pts.device)
+        eng._all_gather(out, pts)
+        return out
 
     for _ in range(a.warmup):
         step()
@@ -537,6 +554,10 @@ def main():
         dist.all_gather_into_tensor(allr, mine)
         per_rank = [float(x) for x in allr.cpu()]
     assert tuple(pts.shape) == (a.batch * world, 17, 3) and bool(torch.isfinite(pts).all())
+    lanes_same = None
+    if lanes_eng is not None:   # the lanes only reschedule: same joints as ONE engine on the same crops
+        lanes_same = bool(torch.equal(pts[rank * a.batch:(rank + 1) * a.batch], net.predict_crops(images, boxes)))
+        assert lanes_same, "lanes changed the joints"
 
     out = None
     if rank == 0:
@@ -555,7 +576,8 @@ def main():
                                       " MFMA (BASELINE configs[2])" if (a.model_name, a.c, a.dtype, world) == ("HRNet", 48, "bf16", 1)
                                       else " MFMA, sharded over %d GPUs (BASELINE configs[3] shape: %d crops per step)" % (world, a.batch * world)
                                       if (a.model_name, a.c, a.dtype) == ("HRNet", 48, "bf16") else ""),
-                       "global_batch": a.batch * world, "micro_batch": a.max_batch,
+                       "global_batch": a.batch * world, "micro_batch": a.max_batch if lanes_eng is None else lanes_eng.max_batch,
+                       "lanes_per_gpu": 1 if lanes_eng is None else a.lanes, "lanes_same_joints_as_one_engine": lanes_same,
                        "parallelism": "dp%d (crop sharding, RCCL all-gather of keypoints)" % world,
                        "weights": "random-init seeded (synth_state_dict seed 0), BN stats randomised"},
             "rccl_ranks": world if dist else 0,

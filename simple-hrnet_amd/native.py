@@ -355,7 +355,9 @@ class MultiDeviceHRNet:
     """One process, several GPUs -- what ``torch.nn.DataParallel(model, device_ids)`` gives a user of the reference
     with ONE call (``SimpleHRNet.py:123-135``), without its per-forward parameter broadcast and heat-map gather:
 
-    * one ``NativeHRNet`` handle per listed device (a device may be listed twice: two handles, two streams);
+    * one ``NativeHRNet`` handle per listed device (a device may be listed twice: two handles, two streams -- "lanes" of one
+      GPU: each lane runs half the batch, and the launches of one fill the drain / tail of the other's, +4 % on a
+      256-crop W48 batch, same joints);
     * weights are folded + packed once (first handle) and copied blob-to-blob to the others;
     * ``predict_crops`` / ``__call__`` / ``predict_frame`` split the packed crop batch (or the frame's detections) into
       contiguous index ranges (``dist.shard_range``), run every range on its device from its own host thread (the C ABI
@@ -418,6 +420,15 @@ class MultiDeviceHRNet:
 
     def load_checkpoint(self, path: str) -> "MultiDeviceHRNet":
         return self.load_state_dict(torch.load(path, map_location="cpu"))
+
+    def adopt_from(self, src: "NativeHRNet") -> "MultiDeviceHRNet":
+        """weights from an engine that already holds them (loaded, or received over RCCL): blob -> blob, no re-packing"""
+        blob = src.weight_blob_tensor()
+        for net in self.nets:
+            net.weight_blob_tensor().copy_(blob)
+            torch.cuda.synchronize(net.torch_device)
+            net.adopt_weights()
+        return self
 
     # -- sharded execution ---------------------------------------------------------------------------------------------
     def _ranges(self, n: int) -> List[Tuple[int, int]]:
