@@ -32,10 +32,14 @@ if len(n96):
         erest = (sel[:, :, 7] & ((1 << 48) - 1)).astype(float)
         print("96-cout form, S=%d (cin %d): %d blocks, %.1f stages, %.1f tiles per block, total/block %.0f ticks (ideal MFMA per stage and SIMD: %d)" % (
             S, 32 * S, len(sel), st[:, 0].mean(), nt[:, 0].mean(), sel[:, 0, 4].mean(), 2 * 18 * (int(sel[0, 0, 6]) - 90) * 16))
+        plan = (sel[:, :, 1] & 0xffffffff).astype(float)
+        pro, pro_issue = (sel[:, :, 1] >> 32).astype(float), (sel[:, :, 3] >> 32).astype(float)
+        ewait = (sel[:, :, 3] & 0xffffffff).astype(float)
+        print("    block prologue (entry -> first stage): %.0f ticks, of which setup + LDS-DMA issue %.0f" % (pro[:, 0].mean(), pro_issue[:, 0].mean()))
         for w in range(8):
-            print("    wave %d: per stage: entry wait %.0f  plan/residual issue %.0f  chunks %.0f | per tile: residual wait %.0f  epilogue rest %.0f" % (
-                w, (sel[:, w, 0] / st[:, w]).mean(), (sel[:, w, 1] / st[:, w]).mean(), (sel[:, w, 2] / st[:, w]).mean(),
-                (sel[:, w, 3] / nt[:, w]).mean(), (erest[:, w] / nt[:, w]).mean()))
+            print("    wave %d: per stage: entry wait %.0f  plan/residual issue %.0f  chunks %.0f | per tile: residual wait %.0f  epilogue rest %.0f | prologue %.0f (issue %.0f)" % (
+                w, (sel[:, w, 0] / st[:, w]).mean(), (plan[:, w] / st[:, w]).mean(), (sel[:, w, 2] / st[:, w]).mean(),
+                (ewait[:, w] / nt[:, w]).mean(), (erest[:, w] / nt[:, w]).mean(), pro[:, w].mean(), pro_issue[:, w].mean()))
     buf[(buf[:, 0, 6] >= 90) & (buf[:, 0, 6] < 100)] = 0
 fz = buf[buf[:, 0, 6] >= 100]   # fused BasicBlock blocks (bbf_run) record their own phases
 if len(fz):
