@@ -119,6 +119,19 @@ int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, in
                          int det_stride, int n, int variant, float *images_dev, int32_t *boxes_host, int32_t *boxes_dev,
                          void *stream);
 
+/* Single-person pre-path on the GPU: replaces, for every frame of a call with multiperson=False,
+ *   cv2.resize(image, (W, H), interpolation=self.interpolation); cv2.cvtColor(image, cv2.COLOR_BGR2RGB); self.transform(image)
+ * (SimpleHRNet.py:213-222 for one frame, :355-366 for a stack; default interpolation cv2.INTER_CUBIC, :27) and writes the
+ * (n,3,H,W) fp32 batch hrn_forward reads.  The boxes of this path are the whole frame: [0, 0, frame_w, frame_h] (:223, :369).
+ *   frames_dev     (n, frame_h, frame_w, 3) uint8 BGR, device
+ *   interpolation  HRN_INTER_* = the cv2.INTER_* value of the same name; anything else fails (the reference would pass it on)
+ * OpenCV is not available where this library is built and tested: the arithmetic follows the published generic 8-bit path of
+ * modules/imgproc/src/resize.cpp (oracle/cv2_resize_oracle.py restates it, the kernel equals that restatement bit for bit);
+ * equality with a given cv2 build -- IPP / OpenCL builds differ among themselves -- is NOT pinned. */
+enum { HRN_INTER_NEAREST = 0, HRN_INTER_LINEAR = 1, HRN_INTER_CUBIC = 2 };
+int hrn_resize_frames(hrn_handle h, const uint8_t *frames_dev, int n, int frame_h, int frame_w, int interpolation,
+                      float *images_dev, void *stream);
+
 /* Flip test-time augmentation + evaluation decode (testing/Test.py:132-140,
  * training/COCO.py:206-230, misc/utils.py:9-29 flip_tensor / flip_back, :125-151 get_max_preds, :154-175 the
  * post-processing of get_final_preds):

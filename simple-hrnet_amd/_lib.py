@@ -91,6 +91,7 @@ SYMBOLS = {
     "hrn_adopt_weights": (ctypes.c_int, [_P]),
     "hrn_weight_blob_read": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int64]),
     "hrn_forward": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P]),
+    "hrn_resize_frames": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "hrn_preprocess_frame": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
     "hrn_forward_flip_tta": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
     "hrn_nms": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]),

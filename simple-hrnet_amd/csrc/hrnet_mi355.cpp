@@ -184,6 +184,8 @@ struct hrn_ctx {
     // crop pre-path scratch (grown on demand, never inside hrn_forward)
     unsigned char *pre_tmp = nullptr;
     size_t pre_tmp_bytes = 0;
+    ResizeTaps *rs_taps = nullptr;   // single-person pre-path: tap tables of the last (frame size, interpolation), device
+    int rs_taps_cap = 0;
     CropParams *pre_params = nullptr;
     int pre_params_cap = 0;
     // pinned host image of one call's crop parameters + boxes (the async uploads read it after the call returned);
@@ -932,6 +934,8 @@ struct hrn_ctx {
             if (blob) (void)hipFree(blob);
             if (tta_hm) (void)hipFree(tta_hm);
             if (pre_tmp) (void)hipFree(pre_tmp);
+            if (rs_taps) (void)hipFree(rs_taps);
+            rs_taps = nullptr, rs_taps_cap = 0;
             if (pre_params) (void)hipFree(pre_params);
             if (part_val) (void)hipFree(part_val);
             if (part_idx) (void)hipFree(part_idx);
@@ -1641,6 +1645,39 @@ int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, in
     if (boxes_host) memcpy(boxes_host, boxes, (size_t)n * 16);
     if (!h->hip_ok(launch_prepath(frame_dev, frame_w, h->pre_params, n, max_h_pad, h->pre_tmp, images_dev, H, W, s),
                    "pre-path launch"))
+        return 8;
+    return 0;
+}
+
+int hrn_resize_frames(hrn_handle h, const uint8_t *frames_dev, int n, int frame_h, int frame_w, int interpolation,
+                      float *images_dev, void *stream) {
+    if (!h) return 1;
+    if (h->plan_only) {
+        h->err = "plan-only handle (device_id < 0): there is no CPU compute path";
+        return 7;
+    }
+    if (interpolation != HRN_INTER_NEAREST && interpolation != HRN_INTER_LINEAR && interpolation != HRN_INTER_CUBIC) {
+        h->err = "interpolation must be HRN_INTER_NEAREST (0), HRN_INTER_LINEAR (1) or HRN_INTER_CUBIC (2)";
+        return 7;
+    }
+    if (n < 0 || frame_h <= 0 || frame_w <= 0 || (n > 0 && (!frames_dev || !images_dev))) {
+        h->err = "bad frames / n";
+        return 7;
+    }
+    if (n == 0) return 0;
+    if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return 6;
+    hipStream_t s = (hipStream_t)stream;
+    const int H = h->H, W = h->W;
+    if (W + H > h->rs_taps_cap) {
+        if (h->rs_taps) {
+            if (!h->hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return 6;
+            (void)hipFree(h->rs_taps);
+            h->rs_taps = nullptr, h->rs_taps_cap = 0;
+        }
+        if (!h->hip_ok(hipMalloc((void **)&h->rs_taps, (size_t)(W + H) * sizeof(ResizeTaps)), "hipMalloc(resize taps)")) return 6;
+        h->rs_taps_cap = W + H;
+    }
+    if (!h->hip_ok(launch_resize_frames(frames_dev, n, frame_h, frame_w, interpolation, h->rs_taps, images_dev, H, W, s), "resize launch"))
         return 8;
     return 0;
 }

@@ -100,6 +100,13 @@ struct CropParams {
 };
 hipError_t launch_prepath(const unsigned char *frame_dev, int frame_w, const CropParams *crops_dev, int n, int max_h_pad,
                           unsigned char *tmp_dev, float *images_dev, int H, int W, hipStream_t s);
+// single-person pre-path (prepath.hip): cv2.resize of whole frames; one entry per output column, then per output row
+struct ResizeTaps {
+    int ofs;       // first source index of the window (may lie outside: replicate border)
+    short c[4];    // fixed-point coefficients, 11 bits
+};
+hipError_t launch_resize_frames(const unsigned char *frames_dev, int n, int src_h, int src_w, int interp, ResizeTaps *taps_dev,
+                                float *images_dev, int H, int W, hipStream_t s);
 
 struct Stem7Args {         // PoseResNet conv1: 3->64 7x7 s2 p3 + BN + ReLU, NCHW fp32 in, flat padded out (poseresnet.py:25-27)
     const float *images;

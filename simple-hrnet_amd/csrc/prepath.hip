@@ -142,4 +142,109 @@ hipError_t launch_prepath(const unsigned char *frame_dev, int frame_w, const Cro
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-person pre-path: cv2.resize(frame, (W, H), interpolation) + BGR -> RGB + ToTensor + Normalize
+// (SimpleHRNet.py:213-222, 355-366) for 8-bit 3-channel frames.  OpenCV is a third-party dependency of the reference that is
+// not in this image: the arithmetic below follows the published generic path of modules/imgproc/src/resize.cpp (fixed-point
+// coefficients of 11 bits, int32 passes; see oracle/cv2_resize_oracle.py, which this kernel matches bit for bit) -- parity
+// with cv2 itself is UNPINNED.
+// Tap tables are formed on the device (no host staging): one thread per output column / row.
+__global__ __launch_bounds__(256) void resize_taps_kernel(int src_w, int src_h, int W, int H, double scale_x, double scale_y,
+                                                          int interp, ResizeTaps *taps) {
+#pragma clang fp contract(off)
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= W + H) return;
+    const bool is_x = t < W;
+    const int d = is_x ? t : t - W, src = is_x ? src_w : src_h;
+    const double scale = is_x ? scale_x : scale_y;
+    ResizeTaps o;
+    o.ofs = 0, o.c[0] = o.c[1] = o.c[2] = o.c[3] = 0;
+    if (interp == 0) {   // resizeNN
+        int s = (int)floor(__dmul_rn((double)d, scale));
+        o.ofs = s < src - 1 ? s : src - 1, o.c[0] = 2048;
+    } else {
+        // (no contraction into fused multiply-adds anywhere: the reference rounds after every operation)
+        float f = (float)__dsub_rn(__dmul_rn(__dadd_rn((double)d, 0.5), scale), 0.5);
+        int s = (int)floorf(f);
+        f = __fsub_rn(f, (float)s);
+        if (interp == 2) {   // interpolateCubic, A = -0.75
+            const float A = -0.75f;
+            const float x1 = __fadd_rn(f, 1.f), xm = __fsub_rn(1.f, f);
+            const float c0 = __fsub_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(A, x1), __fmul_rn(5.f, A)), x1), __fmul_rn(8.f, A)), x1),
+                                       __fmul_rn(4.f, A));
+            const float c1 = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(A, 2.f), f), __fadd_rn(A, 3.f)), f), f), 1.f);
+            const float c2 = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(A, 2.f), xm), __fadd_rn(A, 3.f)), xm), xm), 1.f);
+            const float c3 = __fsub_rn(__fsub_rn(__fsub_rn(1.f, c0), c1), c2);
+            const float c[4] = {c0, c1, c2, c3};
+            o.ofs = s - 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int v = __float2int_rn(__fmul_rn(c[k], 2048.f));   // saturate_cast<short>: nearest, ties to even
+                o.c[k] = (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+            }
+        } else {             // INTER_LINEAR
+            if (is_x && s < 0) s = 0, f = 0.f;
+            if (is_x && s >= src - 1) s = src - 1, f = 0.f;
+            o.ofs = s;
+            o.c[0] = (short)__float2int_rn(__fmul_rn(__fsub_rn(1.f, f), 2048.f));
+            o.c[1] = (short)__float2int_rn(__fmul_rn(f, 2048.f));
+        }
+    }
+    taps[t] = o;
+}
+
+__global__ __launch_bounds__(256) void resize_frames_kernel(const unsigned char *frames, int src_h, int src_w, const ResizeTaps *taps,
+                                                            int interp, float *images, int H, int W) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)H * W) return;
+    const int yy = (int)(idx / W), xx = (int)(idx - (long)yy * W);
+    const unsigned char *src = frames + (size_t)blockIdx.y * src_h * src_w * 3;
+    const ResizeTaps tx = taps[xx], ty = taps[W + yy];
+    const int K = interp == 2 ? 4 : interp == 1 ? 2 : 1;
+    int hor[4][3];
+    for (int r = 0; r < K; ++r) {
+        int y = ty.ofs + r;
+        y = y < 0 ? 0 : y > src_h - 1 ? src_h - 1 : y;                 // replicate border
+        int s0 = 0, s1 = 0, s2 = 0;
+        for (int k = 0; k < K; ++k) {
+            int x = tx.ofs + k;
+            x = x < 0 ? 0 : x > src_w - 1 ? src_w - 1 : x;
+            const unsigned char *px = src + ((size_t)y * src_w + x) * 3;
+            const int a = tx.c[k];
+            s0 += px[0] * a, s1 += px[1] * a, s2 += px[2] * a;
+        }
+        hor[r][0] = s0, hor[r][1] = s1, hor[r][2] = s2;
+    }
+    int v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int o;
+        if (interp == 2) {        // VResizeCubic + FixedPtCast<int, uchar, 22>
+            o = (hor[0][c] * ty.c[0] + hor[1][c] * ty.c[1] + hor[2][c] * ty.c[2] + hor[3][c] * ty.c[3] + (1 << 21)) >> 22;
+        } else if (interp == 1) { // VResizeLinear<uchar, int, short>
+            o = (((ty.c[0] * (hor[0][c] >> 4)) >> 16) + ((ty.c[1] * (hor[1][c] >> 4)) >> 16) + 2) >> 2;
+        } else {
+            o = hor[0][c] >> 11;
+        }
+        v[c] = o < 0 ? 0 : o > 255 ? 255 : o;
+    }
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};  // SimpleHRNet.py:171
+    float *o = images + (size_t)blockIdx.y * 3 * H * W + (size_t)yy * W + xx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float x = (float)v[2 - c] / 255.0f;       // BGR -> RGB, ToTensor
+        o[(size_t)c * H * W] = (x - mean[c]) / stdv[c];  // Normalize
+    }
+}
+
+hipError_t launch_resize_frames(const unsigned char *frames_dev, int n, int src_h, int src_w, int interp, ResizeTaps *taps_dev,
+                                float *images_dev, int H, int W, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const double scale_x = 1.0 / ((double)W / (double)src_w), scale_y = 1.0 / ((double)H / (double)src_h);
+    hipLaunchKernelGGL(resize_taps_kernel, dim3((W + H + 255) / 256), dim3(256), 0, s, src_w, src_h, W, H, scale_x, scale_y, interp, taps_dev);
+    dim3 g((unsigned)(((long)H * W + 255) / 256), n);
+    hipLaunchKernelGGL(resize_frames_kernel, g, dim3(256), 0, s, frames_dev, src_h, src_w, taps_dev, interp, images_dev, H, W);
+    return hipGetLastError();
+}
+
 }  // namespace hrn

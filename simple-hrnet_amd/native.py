@@ -307,6 +307,31 @@ class NativeHRNet:
             self._check(rc, "hrn_preprocess_frame")
         return images, boxes, boxes_dev
 
+    def resize_frames(self, frames, interpolation: int = 2) -> torch.Tensor:
+        """The single-person pre-path (``multiperson=False``, ``SimpleHRNet.py:213-222`` / ``:355-366``) on the GPU:
+        ``cv2.resize(frame, (W, H), interpolation)`` + BGR -> RGB + ToTensor + Normalize for every frame.
+
+        ``frames``: (Hf, Wf, 3) or (n, Hf, Wf, 3) uint8 BGR (host arrays are uploaded once); ``interpolation``: the
+        ``cv2.INTER_*`` value -- 0 nearest, 1 linear, 2 cubic (the reference's default).  Returns (n, 3, H, W) float32 on the GPU.
+        Follows OpenCV's published generic 8-bit path; equality with a particular cv2 build is not pinned (include/hrnet_mi355.h)."""
+        if interpolation not in (0, 1, 2):
+            raise ValueError("interpolation must be cv2.INTER_NEAREST (0), cv2.INTER_LINEAR (1) or cv2.INTER_CUBIC (2)")
+        if not isinstance(frames, torch.Tensor):
+            frames = torch.from_numpy(np.ascontiguousarray(frames))
+        if frames.dim() == 3:
+            frames = frames.unsqueeze(0)
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+            raise ValueError("frames must be (n, H, W, 3) uint8 BGR")
+        frames = frames.to(self.torch_device, non_blocking=True).contiguous()
+        n, h, w = int(frames.shape[0]), *self.resolution
+        images = torch.empty((n, 3, h, w), dtype=torch.float32, device=self.torch_device)
+        if n:
+            with torch.cuda.device(self.device_index):
+                rc = self._lib.hrn_resize_frames(self._h, frames.data_ptr(), n, int(frames.shape[1]), int(frames.shape[2]),
+                                                 int(interpolation), images.data_ptr(), self._stream())
+            self._check(rc, "hrn_resize_frames")
+        return images
+
     def predict_frame(self, frame, detections, return_heatmaps: bool = False, variant: str = "pad"):
         """pre-path + model + decode for one frame: what ``SimpleHRNet._predict_single`` does after the detector.
         Returns ``(boxes (P,4) int32 numpy, pts (P,J,3) on the GPU[, heatmaps])``."""
@@ -465,6 +490,10 @@ class MultiDeviceHRNet:
                     t.record_stream(mine)
             outs.append(out)
         return outs
+
+    def resize_frames(self, frames, interpolation: int = 2) -> torch.Tensor:
+        """single-person pre-path (``NativeHRNet.resize_frames``) on the first device; ``predict_crops`` shards the result"""
+        return self.nets[0].resize_frames(frames, interpolation)
 
     def predict_crops(self, images: torch.Tensor, boxes, return_heatmaps: bool = False):
         n = int(images.shape[0])

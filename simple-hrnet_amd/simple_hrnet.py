@@ -8,8 +8,10 @@ different, and why:
 * the person detector is injected (``detector=``: an object with ``predict_single(image)`` / ``predict(images)``
   returning ``(P, >=4)`` rows ``x1, y1, x2, y2, ...`` or ``None``) -- the reference's YOLOv3 wrapper depends on an
   un-vendored third-party submodule (``models_/detectors/yolo``) and YOLOv5 on ``torch.hub`` (network);
-* ``multiperson=False`` needs frames that already have the model resolution: the reference resizes them with
-  ``cv2.resize(INTER_CUBIC)`` (``:213-218``), which cannot be pinned here (cv2 is absent);
+* ``multiperson=False``: frames of another size than the model resolution are resized on the GPU the way
+  ``cv2.resize(frame, (W, H), interpolation)`` does it (``:213-218``; ``interpolation`` = ``cv2.INTER_NEAREST`` 0 /
+  ``INTER_LINEAR`` 1 / ``INTER_CUBIC`` 2, default cubic as in the reference, anything else raises) -- OpenCV's published generic
+  8-bit arithmetic, NOT pinned against a cv2 build (cv2 is absent here; ``include/hrnet_mi355.h``: ``hrn_resize_frames``);
 * ``dtype`` picks the arithmetic mode of the engine (``"fp32"`` = parity mode, ``"bf16"`` = MFMA bf16);
 * devices: ``'cuda:N'`` is that GPU.  ``'cuda'`` (all GPUs) and ``'cuda:1,2'`` (the listed ones) are, in a plain Python
   process, ONE engine per listed GPU driven from this process (``native.MultiDeviceHRNet``: the crop batch of a
@@ -82,7 +84,10 @@ class SimpleHRNet:
                  yolo_version="v3", yolo_model_def=None, yolo_class_path=None, yolo_weights_path=None, device=None,
                  enable_tensorrt=False, *, detector=None, dtype="fp32"):
         self.c, self.nof_joints, self.checkpoint_path = c, nof_joints, checkpoint_path
-        self.model_name, self.resolution, self.interpolation = model_name, tuple(resolution), interpolation
+        self.model_name, self.resolution = model_name, tuple(resolution)
+        self.interpolation = 2 if interpolation is None else int(interpolation)   # cv2.INTER_CUBIC (SimpleHRNet.py:27)
+        if self.interpolation not in (0, 1, 2):
+            raise ValueError("interpolation: only cv2.INTER_NEAREST (0), cv2.INTER_LINEAR (1) and cv2.INTER_CUBIC (2) are built")
         self.multiperson, self.return_heatmaps = multiperson, return_heatmaps
         self.return_bounding_boxes, self.max_batch_size = return_bounding_boxes, max_batch_size
         if model_name not in ("HRNet", "hrnet", "PoseResNet", "poseresnet", "ResNet", "resnet"):
@@ -120,10 +125,10 @@ class SimpleHRNet:
         return out[0] if len(out) == 1 else out
 
     def _normalise(self, images_bgr: np.ndarray) -> torch.Tensor:
-        """single-person transform for frames that already have the model resolution: BGR -> RGB, ToTensor, Normalize"""
+        """single-person transform (SimpleHRNet.py:213-222 / :355-366): cv2.resize to the model resolution when the frame
+        has another size (on the GPU, ``NativeHRNet.resize_frames``), BGR -> RGB, ToTensor, Normalize"""
         if tuple(images_bgr.shape[-3:-1]) != self.resolution:
-            raise NotImplementedError("multiperson=False on frames of another size needs cv2.resize(INTER_CUBIC) "
-                                      "(SimpleHRNet.py:213-218), which is not reproduced here")
+            return self.model.resize_frames(images_bgr, self.interpolation)
         x = torch.from_numpy(np.ascontiguousarray(images_bgr[..., ::-1])).to(self.device)
         # tensor divisors: torch turns a division by a python scalar into a multiplication by its reciprocal on the GPU,
         # which is not the float32 division ToTensor performs

@@ -1,0 +1,126 @@
+"""Single-person pre-path: ``cv2.resize(frame, (W, H), interpolation)`` + BGR -> RGB + ToTensor + Normalize
+(``SimpleHRNet.py:213-222``, ``:355-366``) as ``hrn_resize_frames`` / ``NativeHRNet.resize_frames``.
+
+OpenCV is absent from this image (a third-party dependency of the reference, ``requirements.txt:5``), so parity with cv2 is
+UNPINNED: ``oracle/cv2_resize_oracle.py`` restates the published generic 8-bit path, the CPU tests below check that
+restatement against what can be derived by hand (identity, constants, the cubic kernel's coefficients, replication, a linear
+ramp, symmetry), and the GPU tests pin the kernel to the restatement bit for bit -- whole frames, every interpolation,
+up- and down-scaling, odd sizes -- and ``SimpleHRNet.predict`` with ``multiperson=False`` on frames of another size to the
+oracle pipeline (restated resize -> oracle model -> decode)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg, state_dict_np
+from oracle import cv2_resize_oracle as cvo
+
+
+def _frame(h, w, seed):
+    rng = np.random.default_rng(seed)
+    smooth = rng.integers(0, 256, (h // 7 + 2, w // 7 + 2, 3)).astype(np.float64)
+    up = np.kron(smooth, np.ones((7, 7, 1)))[:h, :w]
+    return np.clip(up + rng.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)   # edges, texture, saturated pixels
+
+
+def test_cubic_coefficients_are_the_keys_kernel_with_a_minus_three_quarters():
+    c = cvo._cubic_coeffs(np.array([0.0, 0.5, 0.25], np.float32)) * 2048
+    np.testing.assert_array_equal(c[0], [0, 2048, 0, 0])
+    np.testing.assert_array_equal(c[1], [-192, 1216, 1216, -192])          # W(1.5) = -3/32, W(0.5) = 19/32
+    np.testing.assert_array_equal(c[2], [-216, 1800, 536, -72])
+    for x in np.linspace(0, 0.999, 37, dtype=np.float32):
+        _, k = cvo.taps(2, 2, cvo.INTER_CUBIC)                              # (any call: shapes)
+        assert k.shape == (2, 4)
+        assert abs(int(cvo._sat_short(cvo._cubic_coeffs(np.array([x], np.float32)) * np.float32(2048)).sum()) - 2048) <= 2
+
+
+@pytest.mark.parametrize("interp", [cvo.INTER_NEAREST, cvo.INTER_LINEAR, cvo.INTER_CUBIC])
+def test_restatement_properties(interp):
+    img = _frame(37, 53, 1)
+    # same size: a copy; a constant image stays constant at every size (coefficients sum to one, rounding is unbiased)
+    np.testing.assert_array_equal(cvo.resize_u8(img, (37, 53), interp), img)
+    for hw in ((48, 36), (19, 26), (37, 80), (111, 53)):
+        assert (cvo.resize_u8(np.full((20, 30, 3), 137, np.uint8), hw, interp) == 137).all()
+    # channels do not mix, mirrored input gives mirrored output (the sample grid is symmetric)
+    out = cvo.resize_u8(img, (64, 48), interp)
+    np.testing.assert_array_equal(cvo.resize_u8(img[..., ::-1], (64, 48), interp), out[..., ::-1])
+    if interp != cvo.INTER_NEAREST:   # (resizeNN's floor(dx * scale) grid is not symmetric)
+        np.testing.assert_array_equal(cvo.resize_u8(img[:, ::-1], (64, 48), interp), out[:, ::-1])
+        np.testing.assert_array_equal(cvo.resize_u8(img[::-1], (64, 48), interp), out[::-1])
+    # rows and columns separate: resizing one axis at a time through an exact intermediate is only equal for nearest;
+    # the value range is respected everywhere
+    assert out.dtype == np.uint8 and out.shape == (64, 48, 3)
+
+
+def test_known_values():
+    ramp = np.arange(0, 200, 10, dtype=np.uint8)[None, :, None].repeat(4, 0).repeat(3, 2)        # 0, 10, ..., 190 along x
+    # x2 linear: samples at -0.25, 0.25, 0.75, ... -> 0, 2.5, 7.5, 12.5 ...; ties of the >> 2 stage round up; ends replicate
+    lin = cvo.resize_u8(ramp, (4, 40), cvo.INTER_LINEAR)[0, :, 0]
+    np.testing.assert_array_equal(lin[:6], [0, 3, 8, 13, 18, 23])
+    np.testing.assert_array_equal(lin[-2:], [188, 190])
+    # cubic reproduces a linear ramp away from the borders up to its fixed-point rounding
+    cub = cvo.resize_u8(ramp, (4, 40), cvo.INTER_CUBIC)[0, :, 0].astype(int)
+    ideal = (np.arange(40) + 0.5) / 2 - 0.5
+    assert np.abs(cub[4:-4] - 10 * ideal[4:-4]).max() <= 0.5 + 1e-6
+    # integer-factor nearest = pixel repetition
+    img = _frame(9, 11, 3)
+    np.testing.assert_array_equal(cvo.resize_u8(img, (27, 33), cvo.INTER_NEAREST), img.repeat(3, 0).repeat(3, 1))
+    # overshoot next to an edge is clipped to [0, 255]
+    edge = np.zeros((4, 8, 3), np.uint8)
+    edge[:, 4:] = 255
+    out = cvo.resize_u8(edge, (4, 32), cvo.INTER_CUBIC)[0, :, 0]
+    assert out.min() == 0 and out.max() == 255 and (np.diff(out.astype(int))[8:24] >= 0).all()
+
+
+def test_transform_layout():
+    f = _frame(30, 40, 5)
+    x = cvo.single_person_transform(f, (24, 16))
+    assert x.shape == (1, 3, 24, 16) and x.dtype == np.float32
+    r = cvo.resize_u8(f, (24, 16))
+    np.testing.assert_array_equal(x[0, 0], (r[..., 2].astype(np.float32) / np.float32(255) - cvo.MEAN[0]) / cvo.STD[0])   # R first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("interp", [cvo.INTER_NEAREST, cvo.INTER_LINEAR, cvo.INTER_CUBIC])
+def test_kernel_equals_the_restatement(interp):
+    pkg = load_pkg()
+    for (H, W), sizes in (((128, 96), [(480, 640), (97, 61), (128, 96), (131, 1000), (720, 35)]), ((64, 64), [(1080, 1920), (5, 7)])):
+        net = pkg.NativeHRNet(32, 17, (H, W), "fp32", max_batch=2, device=0)
+        for k, (h, w) in enumerate(sizes):
+            frames = np.stack([_frame(h, w, 10 * k + j) for j in range(2)])
+            got = net.resize_frames(frames, interp).cpu().numpy()
+            want = cvo.single_person_transform(frames, (H, W), interp)
+            np.testing.assert_array_equal(got, want, err_msg=f"{(h, w)} -> {(H, W)}, interpolation {interp}")
+        # one frame without the batch axis; an interpolation that is not built
+        one = net.resize_frames(_frame(50, 70, 99), interp)
+        assert one.shape == (1, 3, H, W)
+        with pytest.raises(ValueError):
+            net.resize_frames(_frame(50, 70, 99), 3)
+        net.close()
+
+
+@pytest.mark.gpu
+def test_single_person_predict_on_frames_of_another_size():
+    """SimpleHRNet(multiperson=False).predict on 150x110 frames, model at 128x96: crops = the restated cv2 path, joints =
+    oracle model + decode on those crops (fp32 engine: coordinates identical), boxes = the whole frame as float32 (:223)"""
+    from oracle import hrnet_torch_oracle as oracle
+    pkg = load_pkg()
+    sd = state_dict_np(32, 0)
+    frames = np.stack([_frame(150, 110, s) for s in (1, 2, 3)])
+    model = pkg.SimpleHRNet(32, 17, sd, resolution=(128, 96), multiperson=False, return_heatmaps=True, return_bounding_boxes=True,
+                            device="cuda:0")
+    assert model.interpolation == 2                                            # cv2.INTER_CUBIC, the reference's default
+    hm, boxes, pts = model.predict(frames)
+    crops = cvo.single_person_transform(frames, (128, 96))
+    np.testing.assert_array_equal(model._normalise(frames).cpu().numpy(), crops)
+    want_boxes = np.repeat(np.asarray([[0, 0, 110, 150]], np.float32), 3, axis=0)
+    np.testing.assert_array_equal(boxes, want_boxes)
+    assert boxes.dtype == np.float32 and pts.shape == (3, 1, 17, 3) and hm.shape == (3, 17, 32, 24)
+    hm_o, pts_o = oracle.predict_crops(sd, torch.from_numpy(crops), want_boxes)
+    np.testing.assert_allclose(hm, np.asarray(hm_o), rtol=0, atol=2e-4)
+    np.testing.assert_array_equal(pts[:, 0, :, :2], np.asarray(pts_o)[..., :2])
+    one = model.predict(frames[0])
+    np.testing.assert_array_equal(one[2], pts[0])
+    lin = pkg.SimpleHRNet(32, 17, sd, resolution=(128, 96), multiperson=False, interpolation=1, device="cuda:0")
+    np.testing.assert_array_equal(lin._normalise(frames).cpu().numpy(), cvo.single_person_transform(frames, (128, 96), cvo.INTER_LINEAR))
+    with pytest.raises(ValueError):
+        pkg.SimpleHRNet(32, 17, sd, resolution=(128, 96), multiperson=False, interpolation=4, device="cuda:0")   # cv2.INTER_LANCZOS4

@@ -166,8 +166,8 @@ def test_predict_single_person_paths_equal_reference():
     np.testing.assert_array_equal(boxes, g["boxes"])
     np.testing.assert_allclose(hm, g["heatmaps"], rtol=0, atol=2e-4)
     np.testing.assert_array_equal(pts[..., :2], g["pts"][..., :2])
-    with pytest.raises(NotImplementedError):
-        model.predict(np.zeros((64, 64, 3), np.uint8))
+    # frames of another size are resized on the GPU (tests/test_resize.py); whole-frame box in the frame's own pixels (:223)
+    assert model.predict(np.zeros((64, 80, 3), np.uint8))[1].tolist() == [[0, 0, 80, 64]]
     # stack of 5 through an engine sized for 2 -> the chunk loop of :423-429
     g = golden("w48_128x96_predict_batch5")
     model = pkg.SimpleHRNet(48, 17, state_dict_np(48, 0), resolution=(128, 96), multiperson=False, return_heatmaps=True,
