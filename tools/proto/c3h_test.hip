@@ -66,6 +66,16 @@ static hipError_t launch_h(const Conv3Problem *dp, const int2 *dmap, int blocks,
     conv3x3_n96h_kernel<<<blocks, 256, g_lds, 0>>>(dp, dmap, nb, g_skew);
     return hipGetLastError();
 }
+static hipError_t launch_w(const Conv3Problem *dp, const int2 *dmap, int blocks, int nb) {
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute((const void *)conv3x3_n96w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, N96W_LDS);
+        once = true;
+    }
+    conv3x3_n96w_kernel<<<blocks, 256, N96W_LDS, 0>>>(dp, dmap, nb);
+    return hipGetLastError();
+}
+static int g_wide = 0;   // run_shape(half = true) launches the wide form (512-pixel tiles, one wave per SIMD) instead
 
 struct Shape {
     int c, h, w;
@@ -137,11 +147,11 @@ static int run_shape(const Shape &sh, int nb, bool with_res, int tpb, bool small
         printf("shape unsupported\n");
         return 1;
     }
-    const int bm = half ? 256 : small ? 128 : p.bm;
+    const int bm = half ? (g_wide ? 512 : 256) : small ? 128 : p.bm;
     const int mtiles = (m + bm - 1) / bm;
     std::vector<int2> map;
     const int mgroups = (mtiles + tpb - 1) / tpb;
-    const int RW = half ? 16 : 8;   // blocks of one M group range per round and cout tile
+    const int RW = half && !g_wide ? 16 : 8;   // blocks of one M group range per round and cout tile
     for (int round = 0; round * RW < mgroups; ++round)
         for (int nt = 0; nt < ntiles; ++nt)
             for (int x = 0; x < RW; ++x) {
@@ -155,7 +165,7 @@ static int run_shape(const Shape &sh, int nb, bool with_res, int tpb, bool small
     hipMalloc(&dp, sizeof p), hipMalloc(&dmap, map.size() * sizeof(int2));
     hipMemcpy(dp, &p, sizeof p, hipMemcpyHostToDevice);
     hipMemcpy(dmap, map.data(), map.size() * sizeof(int2), hipMemcpyHostToDevice);
-    hipError_t e = half ? launch_h(dp, dmap, (int)map.size(), nb) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
+    hipError_t e = half ? (g_wide ? launch_w(dp, dmap, (int)map.size(), nb) : launch_h(dp, dmap, (int)map.size(), nb)) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
     hipError_t e2 = hipDeviceSynchronize();
     if (e != hipSuccess || e2 != hipSuccess) {
         printf("launch failed: %s / %s\n", hipGetErrorString(e), hipGetErrorString(e2));
@@ -192,19 +202,19 @@ static int run_shape(const Shape &sh, int nb, bool with_res, int tpb, bool small
     hipEventCreate(&e0), hipEventCreate(&e1);
     float ms = 0;
     if (reps > 0) {
-        for (int i = 0; i < 3; ++i) half ? launch_h(dp, dmap, (int)map.size(), nb) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
+        for (int i = 0; i < 3; ++i) half ? (g_wide ? launch_w(dp, dmap, (int)map.size(), nb) : launch_h(dp, dmap, (int)map.size(), nb)) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
         hipEventRecord(e0);
-        for (int i = 0; i < reps; ++i) half ? launch_h(dp, dmap, (int)map.size(), nb) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
+        for (int i = 0; i < reps; ++i) half ? (g_wide ? launch_w(dp, dmap, (int)map.size(), nb) : launch_h(dp, dmap, (int)map.size(), nb)) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         ms /= reps;
     }
     const double gflop = 2.0 * 9 * C * (double)C * H * W * nb * 1e-9;
-    printf("%s C=%3d %3dx%-3d nb=%3d res=%d tpb=%d bm=%d blocks=%5zu : bad=%ld (first %ld) tail_bad=%ld maxerr=%.4f", half ? "half" : "full", C, H, W, nb, (int)with_res, tpb,
+    printf("%s C=%3d %3dx%-3d nb=%3d res=%d tpb=%d bm=%d blocks=%5zu : bad=%ld (first %ld) tail_bad=%ld maxerr=%.4f", half ? (g_wide ? "wide" : "half") : "full", C, H, W, nb, (int)with_res, tpb,
            bm, map.size(), bad, first_bad, tail_bad, maxerr);
     if (reps > 0) {
-        const int rounds = ((int)map.size() + (half ? 511 : 255)) / (half ? 512 : 256);
+        const int rounds = ((int)map.size() + (half && !g_wide ? 511 : 255)) / (half && !g_wide ? 512 : 256);
         printf("  %.1f us  %.0f TFLOP/s (algorithmic)  [%d round(s) x %d stages: %.2f us per stage]", ms * 1e3, gflop / ms, rounds,
                tpb * slices * 3, ms * 1e3 / (rounds * tpb * slices * 3));
     }
@@ -219,41 +229,54 @@ static int run_shape(const Shape &sh, int nb, bool with_res, int tpb, bool small
 
 int main(int argc, char **argv) {
     const int nb = argc > 1 ? atoi(argv[1]) : 256;
+    const int mode = argc > 2 ? atoi(argv[2]) : 0;   // 0: everything, 1: the wide form only
     int fails = 0;
+    if (mode == 0) {
+        fails += run_shape({96, 48, 36}, 3, true, 2, false, 0);
+        fails += run_shape({96, 48, 36}, 3, false, 1, false, 0);
+        fails += run_shape({192, 24, 18}, 5, true, 3, false, 0);
+        fails += run_shape({384, 12, 9}, 7, true, 1, false, 0);
+        fails += run_shape({96, 16, 12}, 2, true, 1, false, 0);
+    }
+    g_wide = 1;
     fails += run_shape({96, 48, 36}, 3, true, 2, false, 0);
     fails += run_shape({96, 48, 36}, 3, false, 1, false, 0);
     fails += run_shape({192, 24, 18}, 5, true, 3, false, 0);
     fails += run_shape({384, 12, 9}, 7, true, 1, false, 0);
     fails += run_shape({96, 16, 12}, 2, true, 1, false, 0);
-    for (int half = 1; half >= 0; --half) {
-        // same pixels per block in both forms: tpb 2 t of 256 pixels = t of 512
-        fails += run_shape({96, 48, 36}, nb, true, half ? 4 : 2, false, 20, half);
-        fails += run_shape({192, 24, 18}, nb, true, half ? 2 : 1, false, 20, half);
-        fails += run_shape({384, 12, 9}, nb, true, half ? 2 : 1, false, 20, half);
-        fails += run_shape({96, 48, 36}, nb, true, half ? 8 : 4, false, 20, half);
-        fails += run_shape({192, 24, 18}, nb, true, half ? 4 : 2, false, 20, half);
+    g_wide = 0;
+    for (int form = 2; form >= (mode == 0 ? 0 : 2); --form) {   // 2 wide, 1 half, 0 full
+        const int half = form > 0;
+        g_wide = form == 2;
+        const int t = form == 1 ? 2 : 1;   // same pixels per block in all forms
+        fails += run_shape({96, 48, 36}, nb, true, 2 * t, false, 20, half);
+        fails += run_shape({192, 24, 18}, nb, true, 1 * t, false, 20, half);
+        fails += run_shape({384, 12, 9}, nb, true, 1 * t, false, 20, half);
+        fails += run_shape({96, 48, 36}, nb, true, 4 * t, false, 20, half);
+        fails += run_shape({192, 24, 18}, nb, true, 2 * t, false, 20, half);
+        fails += run_shape({384, 12, 9}, 252, true, 1 * t, false, 20, half);
     }
-    // co-resident blocks out of step: 2 nb crops, 8 tiles per half block (two blocks per CU, ~180 us), start delays of
-    // 0..3 x skew ticks of 10 ns (a tile of the 96-channel branch takes ~22 us)
-    for (int skew : {0, 275, 550, 1100}) {
-        g_skew = skew;
-        printf("skew %d ticks: ", skew);
-        fails += run_shape({96, 48, 36}, 2 * nb, true, 8, false, 10, true);
+    g_wide = 0;
+    if (mode == 0) {
+        // co-resident half blocks out of step: 2 nb crops, 8 tiles per half block (two blocks per CU, ~180 us), start delays of
+        // 0..3 x skew ticks of 10 ns (a tile of the 96-channel branch takes ~22 us)
+        for (int skew : {0, 275, 550, 1100}) {
+            g_skew = skew;
+            printf("skew %d ticks: ", skew);
+            fails += run_shape({96, 48, 36}, 2 * nb, true, 8, false, 10, true);
+        }
+        g_skew = 0;
+        fails += run_shape({96, 48, 36}, 2 * nb, true, 4, false, 10, false);
+        // one wave per SIMD: one half block per CU
+        g_lds = 96 * 1024;
+        printf("one block per CU: ");
+        fails += run_shape({96, 48, 36}, nb, true, 8, false, 20, true);
+        printf("one block per CU: ");
+        fails += run_shape({192, 24, 18}, nb, true, 4, false, 20, true);
+        printf("one block per CU: ");
+        fails += run_shape({384, 12, 9}, 252, true, 2, false, 20, true);
+        g_lds = N96H_LDS;
     }
-    g_skew = 0;
-    fails += run_shape({96, 48, 36}, 2 * nb, true, 4, false, 10, false);
-    // one wave per SIMD: one half block per CU
-    g_lds = 96 * 1024;
-    printf("one block per CU: ");
-    fails += run_shape({96, 48, 36}, nb, true, 8, false, 20, true);
-    printf("one block per CU: ");
-    fails += run_shape({192, 24, 18}, nb, true, 4, false, 20, true);
-    printf("one block per CU: ");
-    fails += run_shape({384, 12, 9}, 252, true, 2, false, 20, true);
-    g_lds = N96H_LDS;
-    printf("two blocks per CU: ");
-    fails += run_shape({384, 12, 9}, 252, true, 1, false, 20, true);
-    fails += run_shape({384, 12, 9}, 252, true, 1, false, 20, false);
     printf(fails ? "FAILED (%d)\n" : "all shapes OK\n", fails);
     return fails ? 1 : 0;
 }
