@@ -4,6 +4,7 @@
 #include "../../simple-hrnet_amd/csrc/conv3x3_lds.hip"
 namespace hrn {
 #include "conv3x3_n96h.inc"
+#include "conv3x3_n96l.inc"
 }
 #include <cstdio>
 #include <cstdlib>
@@ -75,7 +76,21 @@ static hipError_t launch_w(const Conv3Problem *dp, const int2 *dmap, int blocks,
     conv3x3_n96w_kernel<<<blocks, 256, N96W_LDS, 0>>>(dp, dmap, nb);
     return hipGetLastError();
 }
-static int g_wide = 0;   // run_shape(half = true) launches the wide form (512-pixel tiles, one wave per SIMD) instead
+static int g_lmr = 6;   // loader-wave form: 6 = 384-pixel tiles, weights 3 stages ahead; 5 = 320-pixel tiles, 5 stages ahead
+static hipError_t launch_l(const Conv3Problem *dp, const int2 *dmap, int blocks, int nb) {
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute((const void *)conv3x3_n96l_kernel<6, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, N96LCfg<6, 4>::LDS);
+        hipFuncSetAttribute((const void *)conv3x3_n96l_kernel<5, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, N96LCfg<5, 6>::LDS);
+        once = true;
+    }
+    if (g_lmr == 5)
+        conv3x3_n96l_kernel<5, 6><<<blocks, 512, N96LCfg<5, 6>::LDS, 0>>>(dp, dmap, nb);
+    else
+        conv3x3_n96l_kernel<6, 4><<<blocks, 512, N96LCfg<6, 4>::LDS, 0>>>(dp, dmap, nb);
+    return hipGetLastError();
+}
+static int g_wide = 0;   // 2: the loader-wave form (conv3x3_n96l.inc: 384-pixel tiles, 8 waves)   // run_shape(half = true) launches the wide form (512-pixel tiles, one wave per SIMD) instead
 
 struct Shape {
     int c, h, w;
@@ -147,7 +162,7 @@ static int run_shape(const Shape &sh, int nb, bool with_res, int tpb, bool small
         printf("shape unsupported\n");
         return 1;
     }
-    const int bm = half ? (g_wide ? 512 : 256) : small ? 128 : p.bm;
+    const int bm = half ? (g_wide == 2 ? 64 * g_lmr : g_wide ? 512 : 256) : small ? 128 : p.bm;
     const int mtiles = (m + bm - 1) / bm;
     std::vector<int2> map;
     const int mgroups = (mtiles + tpb - 1) / tpb;
@@ -165,7 +180,7 @@ static int run_shape(const Shape &sh, int nb, bool with_res, int tpb, bool small
     hipMalloc(&dp, sizeof p), hipMalloc(&dmap, map.size() * sizeof(int2));
     hipMemcpy(dp, &p, sizeof p, hipMemcpyHostToDevice);
     hipMemcpy(dmap, map.data(), map.size() * sizeof(int2), hipMemcpyHostToDevice);
-    hipError_t e = half ? (g_wide ? launch_w(dp, dmap, (int)map.size(), nb) : launch_h(dp, dmap, (int)map.size(), nb)) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
+    hipError_t e = half ? (g_wide == 2 ? launch_l(dp, dmap, (int)map.size(), nb) : g_wide ? launch_w(dp, dmap, (int)map.size(), nb) : launch_h(dp, dmap, (int)map.size(), nb)) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
     hipError_t e2 = hipDeviceSynchronize();
     if (e != hipSuccess || e2 != hipSuccess) {
         printf("launch failed: %s / %s\n", hipGetErrorString(e), hipGetErrorString(e2));
@@ -202,16 +217,16 @@ static int run_shape(const Shape &sh, int nb, bool with_res, int tpb, bool small
     hipEventCreate(&e0), hipEventCreate(&e1);
     float ms = 0;
     if (reps > 0) {
-        for (int i = 0; i < 3; ++i) half ? (g_wide ? launch_w(dp, dmap, (int)map.size(), nb) : launch_h(dp, dmap, (int)map.size(), nb)) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
+        for (int i = 0; i < 3; ++i) half ? (g_wide == 2 ? launch_l(dp, dmap, (int)map.size(), nb) : g_wide ? launch_w(dp, dmap, (int)map.size(), nb) : launch_h(dp, dmap, (int)map.size(), nb)) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
         hipEventRecord(e0);
-        for (int i = 0; i < reps; ++i) half ? (g_wide ? launch_w(dp, dmap, (int)map.size(), nb) : launch_h(dp, dmap, (int)map.size(), nb)) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
+        for (int i = 0; i < reps; ++i) half ? (g_wide == 2 ? launch_l(dp, dmap, (int)map.size(), nb) : g_wide ? launch_w(dp, dmap, (int)map.size(), nb) : launch_h(dp, dmap, (int)map.size(), nb)) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         ms /= reps;
     }
     const double gflop = 2.0 * 9 * C * (double)C * H * W * nb * 1e-9;
-    printf("%s C=%3d %3dx%-3d nb=%3d res=%d tpb=%d bm=%d blocks=%5zu : bad=%ld (first %ld) tail_bad=%ld maxerr=%.4f", half ? (g_wide ? "wide" : "half") : "full", C, H, W, nb, (int)with_res, tpb,
+    printf("%s C=%3d %3dx%-3d nb=%3d res=%d tpb=%d bm=%d blocks=%5zu : bad=%ld (first %ld) tail_bad=%ld maxerr=%.4f", half ? (g_wide == 2 ? "load" : g_wide ? "wide" : "half") : "full", C, H, W, nb, (int)with_res, tpb,
            bm, map.size(), bad, first_bad, tail_bad, maxerr);
     if (reps > 0) {
         const int rounds = ((int)map.size() + (half && !g_wide ? 511 : 255)) / (half && !g_wide ? 512 : 256);
@@ -229,8 +244,38 @@ static int run_shape(const Shape &sh, int nb, bool with_res, int tpb, bool small
 
 int main(int argc, char **argv) {
     const int nb = argc > 1 ? atoi(argv[1]) : 256;
-    const int mode = argc > 2 ? atoi(argv[2]) : 0;   // 0: everything, 1: the wide form only
+    const int mode = argc > 2 ? atoi(argv[2]) : 0;   // 0: half blocks + the shipped form, 1: the wide form only, 2: the loader-wave form (+ shipped)
     int fails = 0;
+    if (mode == 2) {
+        g_wide = 2;
+        const int small_only = argc > 3 ? atoi(argv[3]) : 0;
+        fails += run_shape({96, 16, 12}, 2, true, 1, false, 0);
+        fails += run_shape({96, 48, 36}, 3, true, 2, false, 0);
+        fails += run_shape({96, 48, 36}, 3, false, 1, false, 0);
+        fails += run_shape({192, 24, 18}, 5, true, 3, false, 0);
+        fails += run_shape({384, 12, 9}, 7, true, 1, false, 0);
+        g_lmr = 5;
+        fails += run_shape({96, 16, 12}, 2, true, 1, false, 0);
+        fails += run_shape({96, 48, 36}, 3, true, 2, false, 0);
+        fails += run_shape({96, 48, 36}, 3, false, 1, false, 0);
+        fails += run_shape({192, 24, 18}, 5, true, 3, false, 0);
+        fails += run_shape({384, 12, 9}, 7, true, 1, false, 0);
+        if (!small_only) {
+            for (int mr : {6, 5}) {
+                g_lmr = mr;
+                printf("-- %d-pixel tiles\n", 64 * mr);
+                fails += run_shape({96, 48, 36}, nb, true, mr == 6 ? 6 : 7, false, 20);    // one block per CU: 202 / 208 blocks
+                fails += run_shape({192, 24, 18}, nb, true, mr == 6 ? 3 : 4, false, 20);
+                fails += run_shape({384, 12, 9}, 252, true, mr == 6 ? 2 : 2, false, 20);
+            }
+            g_wide = 0;
+            fails += run_shape({96, 48, 36}, nb, true, 4, false, 20, false);
+            fails += run_shape({192, 24, 18}, nb, true, 2, false, 20, false);
+            fails += run_shape({384, 12, 9}, 252, true, 1, false, 20, false);
+        }
+        printf(fails ? "FAILED (%d)\n" : "all shapes OK\n", fails);
+        return fails ? 1 : 0;
+    }
     if (mode == 0) {
         fails += run_shape({96, 48, 36}, 3, true, 2, false, 0);
         fails += run_shape({96, 48, 36}, 3, false, 1, false, 0);
