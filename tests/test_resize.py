@@ -79,6 +79,22 @@ def test_transform_layout():
     np.testing.assert_array_equal(x[0, 0], (r[..., 2].astype(np.float32) / np.float32(255) - cvo.MEAN[0]) / cvo.STD[0])   # R first
 
 
+def test_no_cpu_path_and_argument_checks():
+    """the C ABI refuses to resize on a plan-only handle (there is no CPU path in the product); the Python wrapper checks its
+    arguments before it gets there"""
+    pkg = load_pkg()
+    net = pkg.NativeHRNet(32, 17, (64, 64), "fp32", max_batch=2, device=-1)
+    rc = net._lib.hrn_resize_frames(net._h, 0, 1, 10, 10, 2, 0, None)
+    assert rc == 7 and b"plan-only" in net._lib.hrn_last_error(net._h)
+    with pytest.raises(ValueError):
+        net.resize_frames(np.zeros((10, 10, 3), np.uint8), 5)
+    with pytest.raises(ValueError):
+        net.resize_frames(np.zeros((10, 10, 4), np.uint8), 2)
+    net.close()
+    with pytest.raises(ValueError):
+        pkg.SimpleHRNet(32, 17, {}, resolution=(64, 64), multiperson=False, interpolation=3, device="cuda:0")   # cv2.INTER_AREA
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("interp", [cvo.INTER_NEAREST, cvo.INTER_LINEAR, cvo.INTER_CUBIC])
 def test_kernel_equals_the_restatement(interp):
