@@ -90,6 +90,7 @@ static hipError_t launch_l(const Conv3Problem *dp, const int2 *dmap, int blocks,
         conv3x3_n96l_kernel<6, 4><<<blocks, 512, N96LCfg<6, 4>::LDS, 0>>>(dp, dmap, nb);
     return hipGetLastError();
 }
+static int g_cold = 0;   // > 1: that many tensor sets in rotation (operands from HBM, not from the Infinity Cache)
 static int g_wide = 0;   // 2: the loader-wave form (conv3x3_n96l.inc: 384-pixel tiles, 8 waves)   // run_shape(half = true) launches the wide form (512-pixel tiles, one wave per SIMD) instead
 
 struct Shape {
@@ -212,18 +213,40 @@ static int run_shape(const Shape &sh, int nb, bool with_res, int tpb, bool small
         if (ho[i] != 0 && ho[i] != 0x7f7f) ++tail_bad;
     for (size_t i = 0; i < (size_t)guard_front * C; ++i)
         if (ho[i] != 0x7f7f) ++tail_bad;
-    // timing
+    // timing.  g_cold > 1: rotate over g_cold sets of (input, residual, output) tensors so that no launch finds its operands in the
+    // 256-MB Infinity Cache -- the condition a convolution meets inside the net, where a layer's tensors total 0.3 GB
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     float ms = 0;
     if (reps > 0) {
-        for (int i = 0; i < 3; ++i) half ? (g_wide == 2 ? launch_l(dp, dmap, (int)map.size(), nb) : g_wide ? launch_w(dp, dmap, (int)map.size(), nb) : launch_h(dp, dmap, (int)map.size(), nb)) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
+        auto launch = [&](const Conv3Problem *dpp) {
+            return half ? (g_wide == 2 ? launch_l(dpp, dmap, (int)map.size(), nb) : g_wide ? launch_w(dpp, dmap, (int)map.size(), nb) : launch_h(dpp, dmap, (int)map.size(), nb))
+                        : launch_conv3x3_lds(dpp, dmap, (int)map.size(), nb, 32, 6, 0);
+        };
+        const int nset = g_cold > 1 ? g_cold : 1;
+        std::vector<Conv3Problem> hp(nset, p);
+        std::vector<uint16_t *> extra;
+        for (int k = 1; k < nset; ++k) {
+            uint16_t *a, *b, *c;
+            hipMalloc(&a, rows * C * 2), hipMalloc(&b, rows * C * 2), hipMalloc(&c, rows * C * 2);
+            hipMemcpy(a, din, rows * C * 2, hipMemcpyDeviceToDevice), hipMemcpy(b, dres, rows * C * 2, hipMemcpyDeviceToDevice);
+            hipMemset(c, 0, rows * C * 2);
+            hp[k].in = a + (size_t)guard_front * C, hp[k].out = c + (size_t)guard_front * C;
+            hp[k].res = with_res ? b + (size_t)guard_front * C : nullptr;
+            extra.push_back(a), extra.push_back(b), extra.push_back(c);
+        }
+        Conv3Problem *dps;
+        hipMalloc(&dps, nset * sizeof(Conv3Problem));
+        hipMemcpy(dps, hp.data(), nset * sizeof(Conv3Problem), hipMemcpyHostToDevice);
+        for (int i = 0; i < 3; ++i) launch(dps + i % nset);
         hipEventRecord(e0);
-        for (int i = 0; i < reps; ++i) half ? (g_wide == 2 ? launch_l(dp, dmap, (int)map.size(), nb) : g_wide ? launch_w(dp, dmap, (int)map.size(), nb) : launch_h(dp, dmap, (int)map.size(), nb)) : launch_conv3x3_lds(dp, dmap, (int)map.size(), nb, 32, 6, 0);
+        for (int i = 0; i < reps; ++i) launch(dps + i % nset);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         ms /= reps;
+        for (auto q : extra) hipFree(q);
+        hipFree(dps);
     }
     const double gflop = 2.0 * 9 * C * (double)C * H * W * nb * 1e-9;
     printf("%s C=%3d %3dx%-3d nb=%3d res=%d tpb=%d bm=%d blocks=%5zu : bad=%ld (first %ld) tail_bad=%ld maxerr=%.4f", half ? (g_wide == 2 ? "load" : g_wide ? "wide" : "half") : "full", C, H, W, nb, (int)with_res, tpb,
@@ -246,6 +269,25 @@ int main(int argc, char **argv) {
     const int nb = argc > 1 ? atoi(argv[1]) : 256;
     const int mode = argc > 2 ? atoi(argv[2]) : 0;   // 0: half blocks + the shipped form, 1: the wide form only, 2: the loader-wave form (+ shipped)
     int fails = 0;
+    if (mode == 3) {   // the forms with their operands in the Infinity Cache (one tensor set) and from HBM (four sets in rotation)
+        for (int cold : {0, 4}) {
+            g_cold = cold;
+            printf("-- %s\n", cold ? "operands from HBM (4 tensor sets in rotation)" : "operands cache-resident (one tensor set)");
+            g_wide = 0;
+            fails += run_shape({96, 48, 36}, nb, true, 4, false, 20, false);
+            fails += run_shape({192, 24, 18}, nb, true, 2, false, 20, false);
+            fails += run_shape({384, 12, 9}, 252, true, 1, false, 20, false);
+            fails += run_shape({96, 48, 36}, nb, true, 8, false, 20, true);
+            fails += run_shape({192, 24, 18}, nb, true, 4, false, 20, true);
+            fails += run_shape({384, 12, 9}, 252, true, 2, false, 20, true);
+            g_wide = 2, g_lmr = 6;
+            fails += run_shape({96, 48, 36}, nb, true, 6, false, 20);
+            fails += run_shape({192, 24, 18}, nb, true, 3, false, 20);
+            fails += run_shape({384, 12, 9}, 252, true, 2, false, 20);
+        }
+        printf(fails ? "FAILED (%d)\n" : "all shapes OK\n", fails);
+        return fails ? 1 : 0;
+    }
     if (mode == 2) {
         g_wide = 2;
         const int small_only = argc > 3 ? atoi(argv[3]) : 0;
