@@ -18,7 +18,8 @@ published generic (non-IPP, non-OpenCL) path of ``modules/imgproc/src/resize.cpp
 
 OpenCV builds that route 8-bit resizes through IPP or OpenCL are documented NOT to be bit-identical to this path; the GPU kernel
 (``simple-hrnet_amd/csrc/prepath.hip: resize_frames_kernel``) is pinned to THIS restatement bit for bit
-(``tests/test_resize.py``), and this restatement to hand-derivable properties only.  Only tests may import this module.
+(``tests/test_resize.py``), and this restatement to hand-derivable properties and to the textbook float formula (Keys kernel, a = -0.75,
+half-pixel centres, replicate border: never more than one grey level away) only.  Only tests may import this module.
 """
 import numpy as np
 

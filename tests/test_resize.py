@@ -71,6 +71,45 @@ def test_known_values():
     assert out.min() == 0 and out.max() == 255 and (np.diff(out.astype(int))[8:24] >= 0).all()
 
 
+def _float_resize(img, out_hw, cubic):
+    """independent float64 statement of the same sampling: half-pixel centres, Keys kernel with a = -0.75 (or the tent), replicate
+    border, separable -- no fixed point anywhere"""
+    def weights(dst, src):
+        f = (np.arange(dst) + 0.5) * (src / dst) - 0.5
+        s = np.floor(f).astype(int)
+        t = f - s
+        if cubic:
+            def W(x):
+                x = np.abs(x)
+                a = -0.75
+                return np.where(x <= 1, (a + 2) * x ** 3 - (a + 3) * x ** 2 + 1, np.where(x < 2, a * x ** 3 - 5 * a * x ** 2 + 8 * a * x - 4 * a, 0.0))
+            idx = s[:, None] + np.arange(-1, 3)[None, :]
+            w = W(t[:, None] - np.arange(-1, 3)[None, :])
+        else:
+            idx = s[:, None] + np.arange(0, 2)[None, :]
+            w = np.stack([1 - t, t], 1)
+        return np.clip(idx, 0, src - 1), w
+    h, w_ = img.shape[:2]
+    yi, wy = weights(out_hw[0], h)
+    xi, wx = weights(out_hw[1], w_)
+    a = img.astype(np.float64)
+    hor = np.einsum("hwkc,wk->hwc", a[:, xi, :], wx)
+    return np.einsum("hkwc,hk->hwc", hor[yi], wy)
+
+
+@pytest.mark.parametrize("interp", [cvo.INTER_LINEAR, cvo.INTER_CUBIC])
+def test_restatement_stays_within_one_grey_level_of_the_float_formula(interp):
+    """the fixed-point path (11-bit coefficients, integer passes) against the textbook float formula it approximates: never more
+    than one grey level apart (after clipping), 0.3 on average -- over up- and down-scaling by odd ratios"""
+    for seed, (h, w), hw in ((1, (37, 53), (96, 72)), (2, (120, 90), (64, 48)), (3, (64, 48), (64, 200)), (4, (9, 200), (33, 17))):
+        img = _frame(h, w, seed)
+        got = cvo.resize_u8(img, hw, interp).astype(np.float64)
+        want = np.clip(_float_resize(img, hw, interp == cvo.INTER_CUBIC), 0, 255)
+        err = np.abs(got - want)
+        assert err.max() <= 1.0 + 1e-9, (seed, err.max())
+        assert err.mean() < 0.35
+
+
 def test_transform_layout():
     f = _frame(30, 40, 5)
     x = cvo.single_person_transform(f, (24, 16))
