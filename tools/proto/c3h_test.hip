@@ -90,6 +90,7 @@ static hipError_t launch_l(const Conv3Problem *dp, const int2 *dmap, int blocks,
         conv3x3_n96l_kernel<6, 4><<<blocks, 512, N96LCfg<6, 4>::LDS, 0>>>(dp, dmap, nb);
     return hipGetLastError();
 }
+static int g_show = 0;   // print that many mismatches per case
 static int g_cold = 0;   // > 1: that many tensor sets in rotation (operands from HBM, not from the Infinity Cache)
 static int g_wide = 0;   // 2: the loader-wave form (conv3x3_n96l.inc: 384-pixel tiles, 8 waves)   // run_shape(half = true) launches the wide form (512-pixel tiles, one wave per SIMD) instead
 
@@ -203,6 +204,7 @@ static int run_shape(const Shape &sh, int nb, bool with_res, int tpb, bool small
             const float err = fabsf(a - b);
             if (!(err <= 0.02f + 0.01f * fabsf(b))) {
                 if (first_bad < 0) first_bad = q * C + c;
+                if (bad < g_show) printf("   bad: row %ld ch %d got %.4f (0x%04x) want %.4f\n", q, c, a, ho[i], b);
                 ++bad;
             }
             if (err > maxerr) maxerr = err;
@@ -291,6 +293,7 @@ int main(int argc, char **argv) {
     if (mode == 2) {
         g_wide = 2;
         const int small_only = argc > 3 ? atoi(argv[3]) : 0;
+        g_show = argc > 4 ? atoi(argv[4]) : 0;
         fails += run_shape({96, 16, 12}, 2, true, 1, false, 0);
         fails += run_shape({96, 48, 36}, 3, true, 2, false, 0);
         fails += run_shape({96, 48, 36}, 3, false, 1, false, 0);
