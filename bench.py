@@ -137,7 +137,12 @@ def _cpu_worker(spec_path):
         if el >= budget_s or done >= 512:
             break
     if spec.get("out"):
-        np.savez(spec["out"], hm=first[0], pts=first[1])
+        extra = {}
+        if spec.get("emulate_bf16"):
+            # the engine-arithmetic restatement (bf16 weights and stored activations, fp32 accumulation) of the same crops:
+            # what the bf16 kernels are pinned to; outside the timed sample
+            extra["emu_hm"] = T.hrnet_forward_engine(sd, crops[:chunk]).numpy()
+        np.savez(spec["out"], hm=first[0], pts=first[1], **extra)
     res = {"value": round(done / el, 3), "unit": "crops/s", "cores": best, "kind": "port", "cpu": model,
            "sample": "%d crops (max_batch_size=%d chunks, SimpleHRNet.py:285-294) of HRNet-W%d %dx%d fp32 incl. decode, "
                      "torch-CPU restatement of the reference device='cpu' path (oracle/hrnet_torch_oracle.py; /root/reference "
@@ -406,6 +411,7 @@ def parity_measure(pkg, net, a, images, boxes, dev, cpu_out):
     k = min(PARITY_CROPS, a.batch)
     ref = np.load(cpu_out)
     ref_hm, ref_pts = ref["hm"][:k], ref["pts"][:k]
+    emu_hm = ref["emu_hm"][:k] if "emu_hm" in ref.files else None
     hm, pts = net.predict_crops(images, boxes, return_heatmaps=True)      # whole batch, as timed
     hm, pts = hm[:k].cpu().numpy(), pts[:k].cpu().numpy()
     del ref
@@ -425,6 +431,19 @@ def parity_measure(pkg, net, a, images, boxes, dev, cpu_out):
            "%s_px_hist" % a.dtype: hist, "%s_px_unit" % a.dtype: "crop pixels, max(|dy|,|dx|) per (crop, joint), %d joints" % am.size,
            "%s_max_abs_dH" % a.dtype: round(float(np.abs(hm - ref_hm).max()), 5), "heatmap_sigma": round(float(ref_hm.std()), 4),
            "%s_coords_identical" % a.dtype: bool(np.array_equal(pts[..., :2], ref_pts[..., :2]))}
+    if emu_hm is not None:
+        # Is the bf16 engine's distance from the fp32 reference bf16 arithmetic, or the kernels?  The emulation IS bf16-storage
+        # arithmetic (oracle/hrnet_torch_oracle.py: EngineEmulation, pinned to the reference tap by tap with its roundings off):
+        # the engine against it, and the emulation's own agreement with the fp32 reference.
+        eflat = emu_hm.reshape(k, hm.shape[1], -1)
+        eam = eflat.argmax(-1)
+        out["bf16_vs_emulation_max_rel"] = round(float(np.abs(hm - emu_hm).max() / np.abs(emu_hm).max()), 6)
+        out["bf16_vs_emulation_max_abs_dH"] = round(float(np.abs(hm - emu_hm).max()), 5)
+        out["bf16_vs_emulation_argmax_agree_frac"] = round(float((am == eam).mean()), 4)
+        out["emulation_vs_fp32_argmax_agree_frac"] = round(float((eam == ram).mean()), 4)
+        out["emulation_vs_fp32_max_abs_dH"] = round(float(np.abs(emu_hm - ref_hm).max()), 5)
+        out["emulation"] = ("bf16-storage arithmetic restated on the CPU: folded weights and every stored activation rounded to "
+                            "bf16, fp32 accumulation; per-stage pins: tests/test_bf16_pin.py")
     if a.dtype != "fp32" and a.model_name == "HRNet":   # the parity mode on the same crops
         f32 = pkg.NativeHRNet(a.c, 17, (a.height, a.width), "fp32", max_batch=k, device=dev.index).load_state_dict(pkg.synth_state_dict(a.c, 17, 0))
         hm32, pts32 = f32.predict_crops(images[:k], boxes[:k], return_heatmaps=True)
@@ -628,7 +647,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline and a.model_name == "HRNet":
             k = min(PARITY_CROPS, a.batch)
             spec = {"c": a.c, "h": a.height, "w": a.width, "budget_s": a.cpu_seconds, "crops": os.path.join(tmpdir, "crops.npy"),
-                    "boxes": boxes_np[:k].tolist(), "out": os.path.join(tmpdir, "ref.npz"), "clip": None}
+                    "boxes": boxes_np[:k].tolist(), "out": os.path.join(tmpdir, "ref.npz"), "clip": None,
+                    "emulate_bf16": a.dtype == "bf16" and a.model_name == "HRNet"}
             np.save(spec["crops"], images[:k].cpu().numpy())
             if not a.no_clip:
                 clip, dets = make_clip()

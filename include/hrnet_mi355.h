@@ -173,6 +173,29 @@ int hrn_pose_similarity(const double *boxes_a, const float *poses_a, int na, con
  * row matched when rows <= cols, otherwise every column; row_to_col[r] = column or -1. */
 int hrn_assignment(const double *cost, int rows, int cols, int32_t *row_to_col);
 
+/* Debug tap -- test infrastructure hook for the per-stage parity tests (tests/test_bf16_pin.py), never needed in production.
+ * The reference's counterpart is a forward hook on a sub-module (`module.register_forward_hook`, torch.nn.Module): the value
+ * of an intermediate of HRNet.forward (models_/hrnet.py:157-189).  A tap is a tensor some launch of the pass writes to HBM:
+ *   "stem"                       conv1 + bn1 + ReLU (hrnet.py:158-160)
+ *   "<state_dict prefix>"        every convolution, e.g. "layer1.0.conv3", "stage3.1.branches.2.0.conv2",
+ *                                "stage4.0.fuse_layers.3.0.2.0", "transition2.2.0.0": its output after the folded BatchNorm,
+ *                                the residual and the ReLU, as stored (bf16 engine: the stored bf16 values, widened exactly)
+ *   "<stage>.fuse.<i>"           the i-th output of a StageModule (hrnet.py:60-69), e.g. "stage3.2.fuse.0"
+ * hrn_forward_tap runs ONE micro-batch (1 <= n <= max_batch) and copies crops crop0, crop0 + crop_step, ... (ncrops of them)
+ * of the named tensor to dst_dev as (ncrops, C, H, W) fp32 right after the launch that completes it; heatmaps_dev
+ * (n,J,h,w) may be NULL.  A tensor
+ * the plan keeps on-chip at this batch size (conv1 of a fused BasicBlock; the projection shortcut of layer1.0) has no tap:
+ * the call fails and says so. */
+typedef struct {
+    char name[96];
+    int32_t c, h, w;
+    int32_t conv_index;   /* index for hrn_get_conv_info, or -1 (stem / fuse outputs) */
+} hrn_tap_info;
+int hrn_tap_count(hrn_handle h);
+int hrn_get_tap_info(hrn_handle h, int index, hrn_tap_info *out);
+int hrn_forward_tap(hrn_handle h, const void *images_dev, int n, const char *tap_name, int crop0, int ncrops, int crop_step,
+                    float *dst_dev, float *heatmaps_dev, void *stream);
+
 /* Introspection used by tests, bench.py and the roofline accounting. */
 int hrn_conv_count(hrn_handle h);
 int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out);

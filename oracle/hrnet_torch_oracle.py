@@ -233,3 +233,194 @@ def poseresnet_forward(sd, x: torch.Tensor, resnet_size: int = 50) -> torch.Tens
         x = F.conv_transpose2d(x, sd["deconv_layers.%d.weight" % (3 * i)], None, 2, 1, 0)
         x = F.relu(_bn_eval(sd, "deconv_layers.%d" % (3 * i + 1), x))
     return F.conv2d(x, sd["final_layer.weight"], sd["final_layer.bias"])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Engine-arithmetic restatement ("bf16 emulation").  The SAME graph as hrnet_forward above (models_/hrnet.py:157-189,
+# :55-71; models_/modules.py:20-40, 56-72), evaluated the way the bf16 engine evaluates it, so that the bf16 HIP kernels
+# can be pinned to an oracle tighter than "a few % of sigma away from the fp32 reference":
+#   * every (conv, BatchNorm) pair folded exactly as hrn_load_weights folds it (simple-hrnet_amd/csrc/hrnet_mi355.cpp
+#     bn_fold / load_weights): scale = gamma / sqrt(var + 1e-5) and shift = beta - mean * scale in float64,
+#     W' = float32(float64(W) * scale), b' = float32(shift);
+#   * round_weights: W' rounded to bf16 (round to nearest even), the head's weights likewise, biases stay fp32;
+#   * round_acts: every tensor the engine writes to HBM is rounded to bf16 at that point -- conv outputs after bias +
+#     residual + ReLU, the fuse sums after their ReLU, the 1x1 fuse convs at low resolution (before the upsample), the
+#     stem's input pixels (the MFMA stem converts the fp32 crops); accumulation is fp32 throughout, heat-maps stay fp32.
+# With both switches off it is the fp32 reference up to the re-association of the BatchNorm fold (tests/test_oracle.py
+# pins that tap by tap against the reference's own forward hooks), which is what pins the emulation itself.
+#
+# The graph is explicit: every stored tensor is a node (named like the engine's taps, include/hrnet_mi355.h) with its
+# operation and the names of its inputs, so that ONE operation can be evaluated on given inputs (``eval_node``): the
+# per-op parity tests (tests/test_bf16_pin.py) feed the engine's own stored inputs of an op to the emulation of that op --
+# the outputs then differ by fp32 summation order only (oneDNN here, the MFMA pipeline there): at most one bf16 ulp on
+# a small fraction of the elements.  End to end the two drift apart like any two bf16 evaluations of a 100-layer net
+# do (a 1-ulp flip changes what every later rounding sees), which is why the end-to-end figures are reported, not pinned.
+def _bf16r(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class EngineEmulation:
+    INPUT = "input"     # the (n,3,H,W) crops
+    HEAD = "heatmaps"   # final_layer output (fp32, never rounded)
+
+    def __init__(self, sd: Dict, round_weights: bool = True, round_acts: bool = True):
+        self.sd, self.rw, self.ra = sd, round_weights, round_acts
+        self.graph: Dict[str, dict] = {}
+        self.order: List[str] = []
+        self._folded: Dict[str, tuple] = {}
+        self._build()
+
+    # ---- graph construction (mirrors HRNet.forward; no arithmetic here)
+    def _node(self, name, **kw):
+        self.graph[name] = kw
+        self.order.append(name)
+        return name
+
+    def _conv(self, conv, bn, x, stride=1, relu=True, res=None):
+        return self._node(conv, op="conv", bn=bn, x=x, stride=stride, relu=relu, res=res)
+
+    def _bottleneck(self, p, x, has_downsample):
+        o = self._conv(p + ".conv1", p + ".bn1", x)
+        o = self._conv(p + ".conv2", p + ".bn2", o)
+        r = x
+        if has_downsample:  # (the bf16 engine computes it inside the chain kernel and rounds it like a stored tensor)
+            r = self._conv(p + ".downsample.0", p + ".downsample.1", x, relu=False)
+        return self._conv(p + ".conv3", p + ".bn3", o, res=r)
+
+    def _stage(self, p, xs, nout):
+        nb = len(xs)
+        ys = []
+        for b in range(nb):
+            y = xs[b]
+            for k in range(4):
+                q = "%s.branches.%d.%d" % (p, b, k)
+                o = self._conv(q + ".conv1", q + ".bn1", y)
+                y = self._conv(q + ".conv2", q + ".bn2", o, res=y)
+            ys.append(y)
+        outs = []
+        for i in range(nout):
+            terms = []
+            for j in range(nb):
+                q = "%s.fuse_layers.%d.%d" % (p, i, j)
+                if i == j:
+                    terms.append((ys[j], 0))
+                elif i < j:   # 1x1 conv + BN stored at low resolution, read upsampled by the fuse (hrnet.py:30-35)
+                    terms.append((self._conv(q + ".0", q + ".1", ys[j], relu=False), j - i))
+                else:         # chain of 3x3 stride-2 convs, ReLU on all but the last (hrnet.py:36-51)
+                    t = ys[j]
+                    for k in range(i - j):
+                        t = self._conv("%s.%d.0" % (q, k), "%s.%d.1" % (q, k), t, stride=2, relu=k < i - j - 1)
+                    terms.append((t, 0))
+            outs.append(self._node("%s.fuse.%d" % (p, i), op="fuse", terms=terms))
+        return outs
+
+    def _build(self):
+        x = self._node("stem", op="stem", x=self.INPUT)
+        x = self._conv("conv2", "bn2", x, stride=2)
+        for k in range(4):
+            x = self._bottleneck("layer1.%d" % k, x, k == 0)
+        xs = [self._conv("transition1.0.0", "transition1.0.1", x), self._conv("transition1.1.0.0", "transition1.1.0.1", x, stride=2)]
+        xs = self._stage("stage2.0", xs, 2)
+        xs = xs + [self._conv("transition2.2.0.0", "transition2.2.0.1", xs[-1], stride=2)]
+        for m in range(4):
+            xs = self._stage("stage3.%d" % m, xs, 3)
+        xs = xs + [self._conv("transition3.3.0.0", "transition3.3.0.1", xs[-1], stride=2)]
+        xs = self._stage("stage4.0", xs, 4)
+        xs = self._stage("stage4.1", xs, 4)
+        xs = self._stage("stage4.2", xs, 1)
+        self._node(self.HEAD, op="head", x=xs[0])
+
+    # ---- arithmetic
+    def _fold(self, conv, bn):
+        if conv not in self._folded:
+            w = _t(self.sd, conv + ".weight").to(torch.float64)
+            g, b = _t(self.sd, bn + ".weight").to(torch.float64), _t(self.sd, bn + ".bias").to(torch.float64)
+            mu, var = _t(self.sd, bn + ".running_mean").to(torch.float64), _t(self.sd, bn + ".running_var").to(torch.float64)
+            scale = g / torch.sqrt(var + 1e-5)
+            shift = b - mu * scale
+            wf = (w * scale.view(-1, 1, 1, 1)).to(torch.float32)
+            if self.rw:
+                wf = _bf16r(wf)
+            self._folded[conv] = (wf, shift.to(torch.float32))
+        return self._folded[conv]
+
+    def _store(self, t):
+        return _bf16r(t) if self.ra else t
+
+    def inputs_of(self, name) -> List[str]:
+        nd = self.graph[name]
+        if nd["op"] == "fuse":
+            return [t for t, _ in nd["terms"]]
+        return [nd["x"]] + ([nd["res"]] if nd.get("res") else [])
+
+    @torch.no_grad()
+    def eval_node(self, name, vals: Dict[str, torch.Tensor], magnitude: bool = False):
+        """the stored value of node ``name`` from the stored values of its inputs (``vals[input name]``).  With
+        ``magnitude`` also the sum of the absolute values of everything that was added up per element (the scale fp32
+        summation noise is proportional to)."""
+        nd = self.graph[name]
+        mag = None
+        if nd["op"] == "stem":
+            x = vals[nd["x"]].to(torch.float32)
+            if self.ra:
+                x = _bf16r(x)   # stem_mfma_kernel: the fp32 crop values become bf16 MFMA operands
+            w, b = self._fold("conv1", "bn1")
+            y = self._store(F.relu(F.conv2d(x, w, b, stride=2, padding=1)))
+            if magnitude:
+                mag = F.conv2d(x.abs(), w.abs(), b.abs(), stride=2, padding=1)
+        elif nd["op"] == "conv":
+            w, b = self._fold(name, nd["bn"])
+            x = vals[nd["x"]]
+            y = F.conv2d(x, w, b, stride=nd["stride"], padding=w.shape[-1] // 2)
+            if magnitude:
+                mag = F.conv2d(x.abs(), w.abs(), b.abs(), stride=nd["stride"], padding=w.shape[-1] // 2)
+            if nd["res"]:
+                y = y + vals[nd["res"]]
+                if magnitude:
+                    mag = mag + vals[nd["res"]].abs()
+            if nd["relu"]:
+                y = F.relu(y)
+            y = self._store(y)
+        elif nd["op"] == "fuse":
+            acc = None
+            for t, shift in nd["terms"]:   # left to right, fp32 (hrnet.py:63-66)
+                v = vals[t]
+                if shift:
+                    v = F.interpolate(v, scale_factor=float(2 ** shift), mode="nearest")
+                acc = v if acc is None else acc + v
+                if magnitude:
+                    mag = v.abs() if mag is None else mag + v.abs()
+            y = self._store(F.relu(acc))
+        else:  # head: final_layer 1x1 conv + bias (hrnet.py:155,187); bf16 weights on the MFMA head, fp32 output
+            wh, bh = _t(self.sd, "final_layer.weight").to(torch.float32), _t(self.sd, "final_layer.bias").to(torch.float32)
+            if self.rw:
+                wh = _bf16r(wh)
+            y = F.conv2d(vals[nd["x"]], wh, bh)
+            if magnitude:
+                mag = F.conv2d(vals[nd["x"]].abs(), wh.abs(), bh.abs())
+        return (y, mag) if magnitude else y
+
+    @torch.no_grad()
+    def forward(self, images, taps=None):
+        """-> heat-maps, or (heat-maps, {name: stored tensor}) for the names in ``taps`` (a set, or "all")"""
+        x = images if isinstance(images, torch.Tensor) else torch.from_numpy(np.asarray(images))
+        vals = {self.INPUT: x.to(torch.float32)}
+        last_use = {}
+        for name in self.order:
+            for i in self.inputs_of(name):
+                last_use[i] = name
+        kept = {}
+        for name in self.order:
+            vals[name] = self.eval_node(name, vals)
+            if taps is not None and name != self.HEAD and (taps == "all" or name in taps):
+                kept[name] = vals[name]
+            for i in self.inputs_of(name):   # free what nobody reads any more
+                if last_use[i] == name and i in vals:
+                    del vals[i]
+        out = vals[self.HEAD]
+        return out if taps is None else (out, kept)
+
+
+def hrnet_forward_engine(sd: Dict, images, round_weights: bool = True, round_acts: bool = True, taps=None):
+    """-> heat-maps (n,J,h,w) fp32, or (heat-maps, {tap name: tensor}) when ``taps`` is given."""
+    return EngineEmulation(sd, round_weights, round_acts).forward(images, taps)

@@ -76,6 +76,11 @@ class ConvInfo(ctypes.Structure):
                 ("flops", ctypes.c_double)]
 
 
+class TapInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 96), ("c", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32),
+                ("conv_index", ctypes.c_int32)]
+
+
 # every symbol include/hrnet_mi355.h declares: (restype, argtypes)
 _P = ctypes.c_void_p
 SYMBOLS = {
@@ -100,6 +105,9 @@ SYMBOLS = {
     "hrn_soft_oks_nms": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, _P, ctypes.c_double]),
     "hrn_pose_similarity": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]),
     "hrn_assignment": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P]),
+    "hrn_tap_count": (ctypes.c_int, [_P]),
+    "hrn_get_tap_info": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(TapInfo)]),
+    "hrn_forward_tap": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
     "hrn_conv_count": (ctypes.c_int, [_P]),
     "hrn_get_conv_info": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ConvInfo)]),
     "hrn_flops_per_crop": (ctypes.c_double, [_P]),

@@ -95,6 +95,19 @@ struct FuseOp {
     int shift[4];
     int nterms;
     int out_t;
+    std::string name;  // "<stage>.fuse.<i>": the i-th output of the module's fuse (debug tap)
+};
+
+// Debug tap (hrn_forward_tap): a tensor some launch of the pass writes to HBM, by name
+struct TapPoint {
+    std::string name;
+    int tensor;     // index into tensors
+    int op;         // the tensor is complete after ops[op]
+    int conv;       // convolution that writes it (-1: stem / fuse)
+};
+struct TapReq {
+    int op, tensor, crop0, ncrops, crop_step;
+    float *dst;
 };
 
 struct Op {
@@ -140,6 +153,7 @@ struct hrn_ctx {
         int conv3, conv1, ds;  // conv3 of Bottleneck b, conv1 of Bottleneck b+1, projection shortcut folded in (or -1)
     };
     std::vector<Chain> chains;
+    std::vector<TapPoint> taps;
     Conv3Problem *probs_dev = nullptr;
     std::vector<Op> ops;
     int stem_out_t = -1, head_in_t = -1;
@@ -333,8 +347,9 @@ struct hrn_ctx {
         }
     }
 
-    int add_fuse(const std::vector<int> &terms, const std::vector<int> &shifts) {
+    int add_fuse(const std::vector<int> &terms, const std::vector<int> &shifts, const std::string &name) {
         FuseOp f;
+        f.name = name;
         f.nterms = (int)terms.size();
         for (int i = 0; i < f.nterms; ++i) f.term_t[i] = terms[i], f.shift[i] = shifts[i];
         const Tensor &t0 = tensors[terms[0]];
@@ -430,7 +445,8 @@ struct hrn_ctx {
                 terms.push_back(i == j ? xs[j] : term[i][j]);
                 shifts.push_back(i < j ? j - i : 0);
             }
-            outs.push_back(add_fuse(terms, shifts));
+            snprintf(buf, sizeof buf, "%s.fuse.%d", name.c_str(), i);
+            outs.push_back(add_fuse(terms, shifts, buf));
         }
         for (int i = 0; i < nout; ++i)
             for (int j = 0; j < nb; ++j)
@@ -575,6 +591,42 @@ struct hrn_ctx {
         ops.push_back({OP_DECODE, 0});
 
         layout_blob();
+    }
+
+    // Every tensor a launch of the pass writes to HBM, by name (hrn_forward_tap): "stem" (conv1 + bn1 + ReLU), every
+    // convolution under its state_dict prefix (its output after bias / residual / ReLU, as stored), "<stage>.fuse.<i>".
+    // A tensor stays intact at least until the op after the one that completed it: buffers are recycled by LATER tensors only.
+    void index_taps() {
+        taps.clear();
+        auto add = [&](const std::string &name, int tensor, int op, int conv) {
+            for (TapPoint &t : taps)
+                if (t.name == name) {  // the four phases of a transposed convolution write one tensor: the last launch completes it
+                    t.op = op;
+                    return;
+                }
+            taps.push_back(TapPoint{name, tensor, op, conv});
+        };
+        for (size_t oi = 0; oi < ops.size(); ++oi) {
+            const Op &op = ops[oi];
+            switch (op.kind) {
+                case OP_STEM:
+                case OP_STEM7: add("stem", stem_out_t, (int)oi, -1); break;
+                case OP_MAXPOOL: add("maxpool", pool_out_t, (int)oi, -1); break;
+                case OP_CONV: add(convs[op.idx].conv, convs[op.idx].out_t, (int)oi, op.idx); break;
+                case OP_CONV3_GROUP:
+                    for (int ci : groups[op.idx].conv_idx) add(convs[ci].conv, convs[ci].out_t, (int)oi, ci);
+                    break;
+                case OP_CONV_GROUP:
+                    for (int ci : dgroups[op.idx].conv_idx) add(convs[ci].conv, convs[ci].out_t, (int)oi, ci);
+                    break;
+                case OP_CHAIN:  // (the projection shortcut folded into the chain kernel is never written)
+                    add(convs[chains[op.idx].conv3].conv, convs[chains[op.idx].conv3].out_t, (int)oi, chains[op.idx].conv3);
+                    add(convs[chains[op.idx].conv1].conv, convs[chains[op.idx].conv1].out_t, (int)oi, chains[op.idx].conv1);
+                    break;
+                case OP_FUSE: add(fuses[op.idx].name, fuses[op.idx].out_t, (int)oi, -1); break;
+                default: break;
+            }
+        }
     }
 
     void layout_blob() {
@@ -1181,7 +1233,7 @@ struct hrn_ctx {
     };
 
     bool run_pass(const float *images, int nb, const void *boxes, int box_dtype, float *pts, float *heatmaps,
-                  hipStream_t s, Timing *tm, int flip = 0) {
+                  hipStream_t s, Timing *tm, int flip = 0, const TapReq *tap = nullptr) {
         if (tm && !hip_ok(hipEventRecord(tm->ev[0], s), "hipEventRecord")) return false;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op &op = ops[oi];
@@ -1325,6 +1377,13 @@ struct hrn_ctx {
                 }
             }
             if (!hip_ok(e, "kernel launch")) return false;
+            if (tap && tap->op == (int)oi) {  // debug tap: the tensor this launch completed, as (ncrops, C, H, W) fp32
+                const Tensor &t = tensors[tap->tensor];
+                TapArgs a;
+                a.in = row0(tap->tensor), a.dst = tap->dst;
+                a.c = t.c, a.h = t.h, a.w = t.w, a.wp = t.wp, a.hpwp = t.hpwp, a.crop0 = tap->crop0, a.ncrops = tap->ncrops, a.crop_step = tap->crop_step;
+                if (!hip_ok(launch_tap(dtype, a, s), "tap launch")) return false;
+            }
             if (tm && !hip_ok(hipEventRecord(tm->ev[oi + 1], s), "hipEventRecord")) return false;
         }
         return true;
@@ -1412,6 +1471,7 @@ int hrn_create_model(hrn_handle *out, int model, int c, int nof_joints, int heig
         }
     }
     h->build_plan();
+    h->index_taps();
     // every conv launcher covers cout in tiles of 16*nr channels: a width that leaves a remainder would silently skip
     // channels (c = 80: 16 of branch 0's 80).  Multiples of 32 and of 48 never do.
     for (const ConvOp &cv : h->convs)
@@ -1680,6 +1740,44 @@ int hrn_resize_frames(hrn_handle h, const uint8_t *frames_dev, int n, int frame_
     if (!h->hip_ok(launch_resize_frames(frames_dev, n, frame_h, frame_w, interpolation, h->rs_taps, images_dev, H, W, s), "resize launch"))
         return 8;
     return 0;
+}
+
+// Debug tap: one micro-batch with the named tensor copied out right after the launch that completes it.
+int hrn_tap_count(hrn_handle h) { return h ? (int)h->taps.size() : 0; }
+
+int hrn_get_tap_info(hrn_handle h, int index, hrn_tap_info *out) {
+    if (!h || !out || index < 0 || index >= (int)h->taps.size()) return 1;
+    const TapPoint &tp = h->taps[index];
+    const Tensor &t = h->tensors[tp.tensor];
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", tp.name.c_str());
+    out->c = t.c, out->h = t.h, out->w = t.w, out->conv_index = tp.conv;
+    return 0;
+}
+
+int hrn_forward_tap(hrn_handle h, const void *images_dev, int n, const char *tap_name, int crop0, int ncrops, int crop_step,
+                    float *dst_dev, float *heatmaps_dev, void *stream) {
+    if (!h) return 1;
+    if (!h->check_forward_args(images_dev, n, nullptr, nullptr, (float *)1)) return 7;
+    if (!tap_name || !dst_dev || n < 1 || n > h->max_batch || crop0 < 0 || ncrops < 1 || crop_step < 1 ||
+        (int64_t)crop0 + (int64_t)(ncrops - 1) * crop_step >= n) {
+        h->err = "hrn_forward_tap: needs a tap name, a destination, 1 <= n <= max_batch and crops crop0, crop0 + step, ... inside the call";
+        return 7;
+    }
+    const TapPoint *tp = nullptr;
+    for (const TapPoint &t : h->taps)
+        if (t.name == tap_name) tp = &t;
+    if (!tp) {
+        h->err = std::string("hrn_forward_tap: no tensor named '") + tap_name + "' is written by this plan";
+        return 7;
+    }
+    if (tp->conv >= 0 && h->fused_now(h->convs[tp->conv], n)) {
+        h->err = std::string("hrn_forward_tap: '") + tap_name + "' stays in LDS at this batch size (fused BasicBlock pass); tap the block's conv2";
+        return 7;
+    }
+    if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return 6;
+    const TapReq req{tp->op, tp->tensor, crop0, ncrops, crop_step, dst_dev};
+    return h->run_pass((const float *)images_dev, n, nullptr, 0, nullptr, heatmaps_dev, (hipStream_t)stream, nullptr, 0, &req) ? 0 : 8;
 }
 
 int hrn_conv_count(hrn_handle h) { return h ? (int)h->convs.size() : 0; }

@@ -172,6 +172,13 @@ struct TtaArgs {           // flip-TTA combine + get_max_preds + quarter-pixel r
 };
 hipError_t launch_tta_decode(const TtaArgs &a, hipStream_t s);
 
+struct TapArgs {           // debug tap: crops crop0, crop0 + crop_step, ... of a flat padded tensor -> (ncrops, c, h, w) fp32
+    const void *in;
+    float *dst;
+    int c, h, w, wp, hpwp, crop0, ncrops, crop_step;
+};
+hipError_t launch_tap(int dtype, const TapArgs &a, hipStream_t s);
+
 hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s);
 // grouped launch of the generic kernel: device-resident ConvArgs[], block map entries (prob | cout tile << 8, M tile)
 hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr, int mr, int wlds,

@@ -1008,6 +1008,32 @@ hipError_t launch_tta_decode(const TtaArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Debug tap (hrn_forward_tap): the stored values of a flat padded NHWC tensor, widened exactly, as NCHW fp32.
+template <int DT>
+__global__ __launch_bounds__(256) void tap_kernel(const TapArgs p) {
+    using T = Tr<DT>;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per = (long)p.c * p.h * p.w;
+    if (idx >= per * p.ncrops) return;
+    const int n = (int)(idx / per);
+    const int rem = (int)(idx - (long)n * per);
+    const int ch = rem / (p.h * p.w), px = rem - ch * (p.h * p.w);
+    const int r = px / p.w, c = px - r * p.w;
+    const typename T::elem *in = (const typename T::elem *)p.in;
+    p.dst[idx] = T::ld(in[((size_t)(p.crop0 + n * p.crop_step) * p.hpwp + (size_t)r * p.wp + c) * p.c + ch]);
+}
+
+hipError_t launch_tap(int dtype, const TapArgs &a, hipStream_t s) {
+    const long total = (long)a.ncrops * a.c * a.h * a.w;
+    if (total <= 0) return hipSuccess;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(tap_kernel<DT_BF16>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(tap_kernel<DT_F32>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t s) {
     const int total = a.n * a.joints;
     if (total <= 0) return hipSuccess;

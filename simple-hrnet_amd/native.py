@@ -341,6 +341,36 @@ class NativeHRNet:
             return boxes, out[1], out[0]
         return boxes, out
 
+    def tap_infos(self) -> List[_lib.TapInfo]:
+        """the tensors ``forward_tap`` can read: name, (c, h, w), index of the convolution that writes it (or -1)"""
+        out = []
+        for i in range(self._lib.hrn_tap_count(self._h)):
+            ti = _lib.TapInfo()
+            self._check(self._lib.hrn_get_tap_info(self._h, i, ctypes.byref(ti)), "hrn_get_tap_info")
+            out.append(ti)
+        return out
+
+    def forward_tap(self, images: torch.Tensor, name: str, crop0: int = 0, ncrops: Optional[int] = None,
+                    return_heatmaps: bool = False, crop_step: int = 1):
+        """Debug tap (the engine's forward hook): ONE micro-batch over ``images`` (n <= max_batch) with the named
+        intermediate tensor of crops ``crop0, crop0 + crop_step, ...`` (``ncrops`` of them) copied out as (ncrops, C, H, W) fp32 -- for the bf16
+        engine the stored bf16 values, widened exactly.  Names: ``tap_infos()`` / include/hrnet_mi355.h."""
+        x = self._images_ptr(images)
+        n = x.shape[0]
+        if ncrops is None:
+            ncrops = (n - crop0 + crop_step - 1) // crop_step
+        info = {t.name.decode(): t for t in self.tap_infos()}.get(name)
+        if info is None:
+            raise KeyError("no tensor named %r is written by this plan" % name)
+        dst = torch.empty((ncrops, info.c, info.h, info.w), dtype=torch.float32, device=x.device)
+        h, w = self.resolution
+        hm = torch.empty((n, self.nof_joints, h // 4, w // 4), dtype=torch.float32, device=x.device) if return_heatmaps else None
+        with torch.cuda.device(self.device_index):
+            self._check(self._lib.hrn_forward_tap(self._h, x.data_ptr(), n, name.encode(), int(crop0), int(ncrops), int(crop_step),
+                                                  dst.data_ptr(), hm.data_ptr() if hm is not None else None, self._stream()),
+                        "hrn_forward_tap")
+        return (dst, hm) if return_heatmaps else dst
+
     def conv_infos(self) -> List[_lib.ConvInfo]:
         out = []
         for i in range(self._lib.hrn_conv_count(self._h)):

@@ -274,6 +274,79 @@ def poseresnet_case(name, size, n, h, w, seed=0):
          pts=ref_decode(y, boxes, h // 4, w // 4))
 
 
+TAP_SAMPLES = 256
+
+
+def tap_sample_index(size):
+    """the elements of a flattened tap the fixture stores (tests/test_oracle.py recomputes the same index)"""
+    return np.unique(np.linspace(0, size - 1, min(size, TAP_SAMPLES)).astype(np.int64))
+
+
+def taps_case(name, c, n, h, w, seed=0):
+    """Intermediate tensors of the reference's HRNet.forward (models_/hrnet.py:157-189), read with forward hooks on the
+    unmodified modules and stored under the engine's tap names (include/hrnet_mi355.h: hrn_forward_tap) -- the pin for
+    the NAMES and the semantics of the taps ("layer1.0.conv3" is the Bottleneck's output after the residual and the ReLU,
+    "stage3.2.fuse.1" the second output of the third stage-3 module, a fuse-up 1x1 conv is read BEFORE its Upsample ...).
+    Per tap: 256 evenly spaced elements + the fp64 sum and absolute sum of the whole tensor."""
+    m = ref_model(c, seed)
+    got = {}
+
+    def keep(tap, relu=False):
+        def hook(mod, inp, out):
+            t = out.detach().clone()     # (the reference's ReLUs are in-place: copy before they run)
+            got[tap] = torch.relu(t) if relu else t
+        return hook
+
+    def keep_list(prefix):
+        def hook(mod, inp, out):
+            for i, t in enumerate(out):
+                got["%s.fuse.%d" % (prefix, i)] = t.detach().clone()
+        return hook
+
+    mods = dict(m.named_modules())
+    mods["bn1"].register_forward_hook(keep("stem", relu=True))
+    mods["bn2"].register_forward_hook(keep("conv2", relu=True))
+    for path, mod in mods.items():
+        cls = type(mod).__name__
+        if cls == "Bottleneck":
+            mods[path + ".bn1"].register_forward_hook(keep(path + ".conv1", relu=True))
+            mods[path + ".bn2"].register_forward_hook(keep(path + ".conv2", relu=True))
+            mod.register_forward_hook(keep(path + ".conv3"))
+            if mod.downsample is not None:
+                mods[path + ".downsample"].register_forward_hook(keep(path + ".downsample.0"))
+        elif cls == "BasicBlock":
+            mods[path + ".bn1"].register_forward_hook(keep(path + ".conv1", relu=True))
+            mod.register_forward_hook(keep(path + ".conv2"))
+        elif cls == "StageModule":
+            mod.register_forward_hook(keep_list(path))
+            nb = len(mod.branches)
+            for i in range(len(mod.fuse_layers)):
+                for j in range(nb):
+                    q = "%s.fuse_layers.%d.%d" % (path, i, j)
+                    if i < j:    # Sequential(conv1x1, bn, Upsample): the engine stores the BN output at low resolution
+                        mods[q + ".1"].register_forward_hook(keep(q + ".0"))
+                    elif i > j:  # Sequential of Sequential(conv3x3 s2, bn[, relu])
+                        for k in range(i - j):
+                            mods["%s.%d" % (q, k)].register_forward_hook(keep("%s.%d.0" % (q, k)))
+    mods["transition1.0"].register_forward_hook(keep("transition1.0.0"))
+    mods["transition1.1"].register_forward_hook(keep("transition1.1.0.0"))
+    mods["transition2.2"].register_forward_hook(keep("transition2.2.0.0"))
+    mods["transition3.3"].register_forward_hook(keep("transition3.3.0.0"))
+    x = torch.from_numpy(synth.synth_crops(n, h, w, seed=21))
+    with torch.no_grad():
+        y = m(x)
+    names = sorted(got)
+    samples, sums, shapes = [], [], []
+    for t in names:
+        a = got[t].numpy().astype(np.float32).ravel()
+        samples.append(a[tap_sample_index(a.size)])
+        sums.append([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
+        shapes.append(list(got[t].shape))
+    save(name, c=c, n=n, h=h, w=w, weight_seed=seed, crop_seed=21, names=np.asarray(names), heatmaps=y.numpy(),
+         offsets=np.cumsum([0] + [len(s_) for s_ in samples]).astype(np.int64), samples=np.concatenate(samples),
+         sums=np.asarray(sums, np.float64), shapes=np.asarray(shapes, np.int64))
+
+
 def nms_boxes(n, seed, frame=(480, 640), crowd=True):
     """random detections: a few clusters of heavily overlapping boxes (what NMS is for) + scattered ones; distinct scores"""
     rng = np.random.default_rng(seed)
@@ -313,6 +386,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "poseresnet":
         poseresnet_case("poseresnet50_128x96_n2", 50, 2, 128, 96, seed=3)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "taps":
+        taps_case("w32_64x64_taps_n1", 32, 1, 64, 64)
+        taps_case("w48_64x64_taps_n1", 48, 1, 64, 64, seed=1)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fliptta":   # only the flip-TTA fixture
         flip_tta_case("w32_128x96_fliptta_n3", 32, 3, 128, 96, seed=2)
         return
@@ -324,6 +401,8 @@ def main():
     flip_tta_case("w32_128x96_fliptta_n3", 32, 3, 128, 96, seed=2)
     poseresnet_case("poseresnet50_128x96_n2", 50, 2, 128, 96, seed=3)
     nms_case("nms_cases")
+    taps_case("w32_64x64_taps_n1", 32, 1, 64, 64)
+    taps_case("w48_64x64_taps_n1", 48, 1, 64, 64, seed=1)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,253 @@
+"""The bf16 hot path pinned to an oracle, operation by operation (VERDICT r2 "Next round" item 1).
+
+The bf16 kernels -- the whole timed path: ``conv3x3_lds_kernel<48,3>`` with the 96-cout form and the fused BasicBlock pass,
+``conv3x3_lds_kernel<32,*>``, the chain kernels, the MFMA stem / head, the generic kernel's bf16 instantiations, the
+stride-2 slab kernel -- never run in fp32 mode, so the fp32 parity tests say nothing about them.  Here every tensor the
+engine writes to HBM is read back through the debug tap of the C ABI (``hrn_forward_tap``) and every OPERATION of the graph
+is checked on its own: the engine's stored inputs of the op go into the engine-arithmetic restatement of the reference
+(``oracle/hrnet_torch_oracle.py: EngineEmulation`` -- folded weights and stored activations rounded to bf16, fp32
+accumulation; pinned to the REFERENCE tap by tap with its roundings off, tests/test_oracle.py) and the result is compared
+with what the engine stored for that op.  The two differ by fp32 summation order only (oneDNN there, the MFMA pipeline
+here), so per element
+
+    |native - emulation| <= one bf16 ulp of the value  +  2^-16 * (sum of |terms| that were added up),
+
+and only a small fraction of the elements may differ at all.  A dropped K chunk, a wrong pad mask, a stale tile, a
+missing residual are orders of magnitude above that.  Tensors the plan keeps on-chip (conv1 of a fused BasicBlock, the
+projection shortcut inside the chain kernel) are emulated from THEIR inputs, so the fused kernels are checked as what
+they are: two operations with one rounding in between.
+
+End to end the engine and the emulation drift apart like any two bf16 evaluations of a 100-layer net (a 1-ulp flip
+changes what every later rounding sees): that figure is printed and loosely bounded, and bench.py reports it next to
+the emulation's own distance from the fp32 reference (``parity.bf16_vs_emulation_*``).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg, state_dict_np
+
+pytestmark = pytest.mark.gpu
+
+ULP = 2.0 ** -7          # adjacent bf16 values a < b: (b - a) / b <= 2^-7
+NOISE = 2.0 ** -16       # fp32 accumulation of up to ~3.5k terms in two different orders, relative to sum |terms|
+MAX_DIFF_FRAC = 0.01     # elements of one tensor that may differ at all
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_pkg()
+    assert torch.cuda.is_available(), "GPU tests need a GPU: the HIP path has no CPU fallback"
+    return p
+
+
+def _T():
+    from oracle import hrnet_torch_oracle as T
+    return T
+
+
+ENV_KEYS = ("HRN_DISABLE_N96", "HRN_BBF", "HRN_BBF_MIN_TILES", "HRN_DISABLE_LDS", "HRN_DISABLE_LDS32", "HRN_DISABLE_CHAIN",
+            "HRN_DISABLE_CHAIN_DS", "HRN_DISABLE_S2", "HRN_DISABLE_STEM_MFMA", "HRN_DISABLE_HEAD_MFMA", "HRN_DISABLE_GROUP",
+            "HRN_DISABLE_DGROUP", "HRN_SMALL_TILES")
+
+
+def _clear(monkeypatch):
+    for k in ENV_KEYS:
+        monkeypatch.delenv(k, raising=False)
+
+
+class Pinner:
+    """per-op comparison of one engine (one plan variant, one call) with the emulation"""
+
+    def __init__(self, pkg, net, emu, crops_dev, crop0=0, ncrops=None, crop_step=1):
+        self.net, self.emu, self.x = net, emu, crops_dev
+        n = crops_dev.shape[0]
+        self.sel = dict(crop0=crop0, ncrops=ncrops if ncrops is not None else (n - crop0 + crop_step - 1) // crop_step, crop_step=crop_step)
+        self.idx = [crop0 + k * crop_step for k in range(self.sel["ncrops"])]
+        self.tapped = {t.name.decode() for t in net.tap_infos()}
+        self.cache = {emu.INPUT: crops_dev[self.idx].cpu()}
+        self.stats = []
+        self.hm = None
+
+    def native(self, name):
+        """the engine's stored tensor, or None when this plan keeps it on-chip at this batch size"""
+        if name not in self.cache:
+            if name not in self.tapped:
+                self.cache[name] = None
+            else:
+                try:
+                    t, self.hm = self.net.forward_tap(self.x, name, return_heatmaps=True, **self.sel)
+                    self.cache[name] = t.cpu()
+                except RuntimeError as e:
+                    if "stays in LDS" not in str(e):
+                        raise
+                    self.cache[name] = None
+        return self.cache[name]
+
+    def inputs(self, name):
+        """name -> tensor for every input of the op: the engine's own stored values; an input that is never stored is
+        emulated from ITS (stored) inputs"""
+        vals = {}
+        for i in self.emu.inputs_of(name):
+            v = self.native(i)
+            if v is None:
+                v = self.emu.eval_node(i, self.inputs(i))
+            vals[i] = v
+        return vals
+
+    def check(self, name, got=None):
+        got = self.native(name) if got is None else got
+        if got is None:
+            return False
+        want, mag = self.emu.eval_node(name, self.inputs(name), magnitude=True)
+        got, want, mag = got.double(), want.double(), mag.double()
+        d = (got - want).abs()
+        bound = ULP * torch.maximum(got.abs(), want.abs()) + NOISE * mag
+        frac = float((d > 0).double().mean())
+        over = d > bound
+        self.stats.append((name, float((d / bound.clamp_min(1e-30)).max()), frac))
+        assert not bool(over.any()), "%s: %d of %d elements beyond one bf16 ulp (worst %.3g x the bound; |d| max %.4g at |x| max %.4g); %.3f %% differ at all" % (
+            name, int(over.sum()), d.numel(), float((d / bound.clamp_min(1e-30)).max()), float(d.max()), float(want.abs().max()), 100 * frac)
+        assert frac <= MAX_DIFF_FRAC, "%s: %.2f %% of the elements differ from the emulation (allowed %.2f %%)" % (name, 100 * frac, 100 * MAX_DIFF_FRAC)
+        return True
+
+    def check_all(self, names=None):
+        done = 0
+        for name in (names if names is not None else self.emu.order):
+            if name == self.emu.HEAD:
+                continue
+            done += self.check(name)
+        # the head: fp32 heat-maps of the same call
+        assert self.hm is not None
+        self.check(self.emu.HEAD, got=self.hm[self.idx].cpu())
+        return done + 1
+
+    def report(self, tag):
+        worst = max(self.stats, key=lambda s: s[1])
+        fr = [s[2] for s in self.stats]
+        print("\n[bf16 pin, per op] %s: %d ops; worst %s at %.2f of its bound; elements that differ at all: mean %.4f %%, worst %.3f %% (%s)"
+              % (tag, len(self.stats), worst[0], worst[1], 100 * float(np.mean(fr)), 100 * max(fr), max(self.stats, key=lambda s: s[2])[0]))
+
+
+@pytest.mark.parametrize("c,h,w,n", [(48, 128, 96, 3), (32, 128, 96, 2), (48, 64, 64, 1)])
+def test_every_operation_of_a_small_call_meets_the_emulation(pkg, monkeypatch, c, h, w, n):
+    """ALL operations (every convolution, every fuse, stem, head) of a small call: 128-pixel tiles, plain BasicBlock
+    launches; W48 (96-cout form + (48,3) form) and W32 (32-channel-slice forms)."""
+    _clear(monkeypatch)
+    T = _T()
+    emu = T.EngineEmulation(pkg.synth.to_torch_state_dict(state_dict_np(c)))
+    net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=n, device=0).load_state_dict(state_dict_np(c))
+    pin = Pinner(pkg, net, emu, torch.from_numpy(pkg.synth_crops(n, h, w, seed=5)).cuda())
+    assert pin.check_all() >= 300
+    pin.report("W%d %dx%d n=%d" % (c, h, w, n))
+    net.close()
+
+
+VARIANTS = {"default": {}, "no_n96": {"HRN_DISABLE_N96": "1"}, "no_bbf": {"HRN_BBF": "0"}, "no_s2": {"HRN_DISABLE_S2": "1"},
+            "generic_only": {"HRN_DISABLE_LDS": "1", "HRN_DISABLE_S2": "1", "HRN_DISABLE_CHAIN": "1"}}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_batch256_w48_384x288_every_operation(pkg, monkeypatch, variant):
+    """BASELINE configs[2]'s code path itself: ONE micro-batch of 256 crops of W48 384x288 (512 / 384-pixel tiles, the
+    fused BasicBlock pass, the 96-cout form, long + short blocks, the stride-2 slab kernel), three crops from both ends and
+    the middle of the batch, EVERY operation of the graph -- each form of the hot kernels against the EMULATION, not
+    against each other: as shipped; 96-cout form off ((48,3) form everywhere); fused pass off; stride-2 slab kernel off;
+    everything on the generic kernel."""
+    _clear(monkeypatch)
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    T = _T()
+    c, h, w, n = 48, 384, 288, 256
+    g = torch.Generator(device="cuda").manual_seed(1234)                       # bench.py's rank-0 batch
+    crops = torch.randn((n, 3, h, w), generator=g, device="cuda", dtype=torch.float32)
+    emu = T.EngineEmulation(pkg.synth.to_torch_state_dict(state_dict_np(c)))
+    net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=n, device=0).load_state_dict(state_dict_np(c))
+    algos = [i.algo for i in net.conv_infos()]
+    if variant == "default":
+        assert algos.count(2) == 64 and algos.count(3) >= 144          # the fused pass and the 96-cout form are in play
+    if variant == "no_n96":
+        assert algos.count(3) == 0
+    if variant == "no_bbf":
+        assert algos.count(2) == 0
+    if variant == "generic_only":
+        assert set(algos) == {0}
+    pin = Pinner(pkg, net, emu, crops, crop0=1, ncrops=3, crop_step=127)       # crops 1, 128, 255
+    pin.check_all()
+    pin.report("W48 384x288 micro-batch 256, %s" % variant)
+    # end to end (informational + a loose bound): the engine against the emulation run from the crops
+    e2e = emu.forward(crops[pin.idx].cpu())
+    hm = pin.hm[pin.idx].cpu()
+    drift = float((hm - e2e).abs().max() / e2e.abs().max())
+    agree = float((hm.flatten(2).argmax(-1) == e2e.flatten(2).argmax(-1)).float().mean())
+    print("[bf16 pin, end to end] %s: max |dH| / max|H| = %.4f, arg-max agreement with the emulation %.3f" % (variant, drift, agree))
+    assert drift < 0.1
+    net.close()
+
+
+def test_single_crop_w48_384x288_every_operation(pkg, monkeypatch):
+    """n = 1 at full resolution: the small-tile modes of every kernel."""
+    _clear(monkeypatch)
+    T = _T()
+    c, h, w = 48, 384, 288
+    emu = T.EngineEmulation(pkg.synth.to_torch_state_dict(state_dict_np(c)))
+    net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=1, device=0).load_state_dict(state_dict_np(c))
+    pin = Pinner(pkg, net, emu, torch.from_numpy(pkg.synth_crops(1, h, w, seed=9)).cuda())
+    pin.check_all()
+    pin.report("W48 384x288 n=1")
+    net.close()
+
+
+def test_fused_basicblock_pass_on_a_small_call(pkg, monkeypatch):
+    """the fused pass forced on for a mid-sized call (HRN_BBF_MIN_TILES=1): conv1 never reaches HBM, conv2 is checked from
+    the block's input through two emulated convolutions."""
+    _clear(monkeypatch)
+    monkeypatch.setenv("HRN_BBF_MIN_TILES", "1")
+    T = _T()
+    c, h, w, n = 48, 256, 192, 5
+    emu = T.EngineEmulation(pkg.synth.to_torch_state_dict(state_dict_np(c)))
+    net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=n, device=0).load_state_dict(state_dict_np(c))
+    pin = Pinner(pkg, net, emu, torch.from_numpy(pkg.synth_crops(n, h, w, seed=11)).cuda())
+    names = [nm for nm in emu.order if ".branches.0." in nm]
+    assert pin.native("stage3.1.branches.0.2.conv1") is None        # kept in LDS
+    pin.check_all(names)
+    pin.report("W48 256x192 n=5, fused pass forced, branch 0")
+    net.close()
+
+
+def test_fp32_engine_taps_meet_the_unrounded_emulation(pkg, monkeypatch):
+    """the same taps in fp32 mode against the emulation with its roundings off (= the reference, tests/test_oracle.py):
+    the tap plumbing and every fp32 kernel, end to end at every stored tensor, 1e-4 of the tensor's range."""
+    _clear(monkeypatch)
+    T = _T()
+    c, h, w, n = 48, 128, 96, 2
+    crops = torch.from_numpy(pkg.synth_crops(n, h, w, seed=6))
+    sd = pkg.synth.to_torch_state_dict(state_dict_np(c))
+    emu_hm, emu = T.hrnet_forward_engine(sd, crops, round_weights=False, round_acts=False, taps="all")
+    net = pkg.NativeHRNet(c, 17, (h, w), "fp32", max_batch=n, device=0).load_state_dict(state_dict_np(c))
+    x = crops.cuda()
+    worst = 0.0
+    for t in net.tap_infos():
+        name = t.name.decode()
+        got, want = net.forward_tap(x, name).cpu(), emu[name]
+        rel = float((got - want).abs().max() / want.abs().max())
+        worst = max(worst, rel)
+        assert rel < 1e-4, (name, rel)
+    print("\n[fp32 taps] worst relative deviation over %d taps: %.3g" % (len(net.tap_infos()), worst))
+    net.close()
+
+
+def test_tap_refuses_tensors_kept_on_chip(pkg, monkeypatch):
+    _clear(monkeypatch)
+    monkeypatch.setenv("HRN_BBF_MIN_TILES", "1")
+    c, h, w, n = 48, 128, 96, 2
+    net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=n, device=0).load_state_dict(state_dict_np(c))
+    x = torch.from_numpy(pkg.synth_crops(n, h, w)).cuda()
+    with pytest.raises(RuntimeError, match="stays in LDS"):
+        net.forward_tap(x, "stage2.0.branches.0.0.conv1")
+    net.forward_tap(x, "stage2.0.branches.0.0.conv2")           # the block's output is stored
+    with pytest.raises(KeyError):
+        net.forward_tap(x, "layer1.0.downsample.0")             # folded into the chain kernel
+    with pytest.raises(RuntimeError, match="inside the call"):
+        net.forward_tap(x, "stem", crop0=1, ncrops=2)
+    net.close()
