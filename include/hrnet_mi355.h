@@ -50,7 +50,7 @@ typedef struct {
     int32_t in_h, in_w, out_h, out_w;
     int32_t kpad;         /* K = ksize*ksize*cin rounded up to the MFMA K-chunk                 */
     int32_t nr;           /* 16-wide cout fragments per group (packing parameter)              */
-    int32_t algo;         /* 0 generic MFMA kernel, 1 pipelined LDS-staged 3x3 stride-1 kernel, 2 = 1 as half of a fused BasicBlock (HRN_BBF=1), 3 = the 96-cout form of 1 (ks 32, nr 6) */
+    int32_t algo;         /* 0 generic MFMA kernel, 1 pipelined LDS-staged 3x3 stride-1 kernel, 2 = 1 as half of a fused BasicBlock (HRN_BBF=1), 3 = the 96-cout form of 1 (ks 32, nr 6), 4 = generic plan + the stride-2 slab kernel (conv_s2.hip) for calls large enough */
     int32_t ks;           /* algo 1: input channels per LDS slice (k = tap*ks + ci inside one)  */
     int64_t w_offset;     /* byte offset of the packed weights in the blob                     */
     int64_t w_bytes;
@@ -219,6 +219,12 @@ int hrn_plan_block_map(hrn_handle h, int group, int n, int reverse, int32_t *blo
  * 64 * (fragments per wave chosen for n). */
 int hrn_plan_direct_map(hrn_handle h, int group, int n, int32_t *blocks, int capacity, int32_t *members, int member_capacity,
                         int32_t *pixels_per_tile);
+/* Likewise for the `group`-th launch of the stride-2 slab kernel (conv_s2.hip): per block three int32 (problem, tiles walked,
+ * first tile; a tile = `rows` output rows of one image, numbered image-major); per part five int32 (problem, convolution
+ * index, 48-cout tile of it, output rows per tile, tiles per image); *active = 1 when a call of n crops takes this kernel
+ * (0: too few tiles, the same convolutions run on the generic kernel).  Returns blocks | (parts << 20), -1 for a bad group / n. */
+int hrn_plan_s2_map(hrn_handle h, int group, int n, int32_t *blocks, int capacity, int32_t *parts, int part_capacity,
+                    int32_t *active);
 /* per-kernel HIP-event timing of one pass (dominant-kernel roofline in bench.py):
  * runs one micro-batch of n crops and returns, for conv i, its device time in ms. */
 int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms, int conv_ms_len,

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libhrnet_mi355.so")
-SOURCES = ["kernels.hip", "conv3x3_lds.hip", "bottleneck_chain.hip", "prepath.hip", "nms.hip", "postproc.cpp", "hrnet_mi355.cpp"]
+SOURCES = ["kernels.hip", "conv3x3_lds.hip", "conv_s2.hip", "bottleneck_chain.hip", "prepath.hip", "nms.hip", "postproc.cpp", "hrnet_mi355.cpp"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv3x3_n96.inc"), os.path.join(INCLUDE, "hrnet_mi355.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
@@ -116,6 +116,7 @@ SYMBOLS = {
     "hrn_launches_per_pass": (ctypes.c_int, [_P]),
     "hrn_plan_block_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int]),
     "hrn_plan_direct_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, _P]),
+    "hrn_plan_s2_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, _P]),
     "hrn_profile_pass": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
                                         ctypes.POINTER(ctypes.c_float), _P]),
     "hrn_version": (ctypes.c_char_p, []),

@@ -37,7 +37,7 @@ struct Buffer {
     bool in_use = false;
 };
 
-enum OpKind { OP_STEM, OP_STEM7, OP_MAXPOOL, OP_CONV, OP_CONV3_GROUP, OP_CONV_GROUP, OP_CHAIN, OP_FUSE, OP_HEAD, OP_DECODE };
+enum OpKind { OP_STEM, OP_STEM7, OP_MAXPOOL, OP_CONV, OP_CONV3_GROUP, OP_CONV_GROUP, OP_S2_GROUP, OP_CHAIN, OP_FUSE, OP_HEAD, OP_DECODE };
 
 struct ConvOp {
     std::string conv, bn;  // state_dict prefixes ("" bn => plain bias conv)
@@ -51,6 +51,10 @@ struct ConvOp {
     int fuse_with = -1;    // conv1 of a BasicBlock that can also compute this conv2 (conv3x3_lds.hip: bbf_run)
     bool fused_away = false;  // conv2 of such a block: skipped in its own launch whenever conv1's launch ran fused
     int64_t w_off = 0, w_bytes = 0, b_off = 0;
+    // stride-2 slab kernel (conv_s2.hip): 3x3 / stride 2 / 48 input channels in bf16.  Such a convolution keeps its generic
+    // plan (the small-call fallback, bit-identical) and carries a second weight image, the (48, 3) LDS form, for the slab kernel
+    bool s2 = false;
+    int64_t w2_off = 0, w2_bytes = 0;
     double flops = 0;
 };
 
@@ -90,6 +94,29 @@ struct DirectGroup {
     std::vector<int2> map_host;  // scratch of direct_group_blocks()
 };
 
+struct Op {
+    OpKind kind;
+    int idx;  // index into convs / fuses
+};
+
+// a set of stride-2 convolutions with 48 input channels issued as ONE launch of the slab kernel (conv_s2.hip): one problem
+// per (input tensor, up to 8 parts of 48 output channels); `fallback` = the same convolutions on the generic kernel, taken
+// when the call has too few tiles to fill the chip (same K order and arithmetic: bit-identical)
+struct S2Group {
+    struct Prob {
+        int in_t;
+        std::vector<std::pair<int, int>> parts;  // (convolution, 48-cout tile of it)
+        int rows = 1, tiles_per_image = 1;
+    };
+    std::vector<int> conv_idx;
+    std::vector<Prob> probs;
+    std::vector<Op> fallback;
+    int prob_first = 0;
+    int64_t map_capacity = 0;
+    MapSlot slot[kMapSlots];
+    std::vector<int2> map_host;
+};
+
 struct FuseOp {
     int term_t[4];
     int shift[4];
@@ -108,11 +135,6 @@ struct TapPoint {
 struct TapReq {
     int op, tensor, crop0, ncrops, crop_step;
     float *dst;
-};
-
-struct Op {
-    OpKind kind;
-    int idx;  // index into convs / fuses
 };
 
 // x / d == (x * magic) >> shift for 0 <= x < 2^27
@@ -149,6 +171,8 @@ struct hrn_ctx {
     std::vector<FuseOp> fuses;
     std::vector<Conv3Group> groups;
     std::vector<DirectGroup> dgroups;
+    std::vector<S2Group> s2groups;
+    S2Problem *s2probs_dev = nullptr;
     struct Chain {
         int conv3, conv1, ds;  // conv3 of Bottleneck b, conv1 of Bottleneck b+1, projection shortcut folded in (or -1)
     };
@@ -183,7 +207,12 @@ struct hrn_ctx {
     // 1: convolutions that read the same tensor share one cout-tile width so that they can share a launch (and L2)
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
-    bool disable_n96 = getenv("HRN_DISABLE_N96") != nullptr;   // 96-cout form off: those convolutions take the (48, 3) form
+    bool disable_n96 = getenv("HRN_DISABLE_N96") != nullptr;
+    // stride-2 slab kernel (conv_s2.hip) off: those convolutions stay on the generic kernel (bit-identical results)
+    bool disable_s2 = getenv("HRN_DISABLE_S2") != nullptr;
+    // the slab kernel is taken when a launch has at least this many tiles (one per CU); smaller calls use the generic kernel
+    int s2_min_tiles = getenv("HRN_S2_MIN_TILES") ? atoi(getenv("HRN_S2_MIN_TILES")) : 256;
+    int s2_target_blocks = getenv("HRN_S2_BLOCKS") ? std::max(1, atoi(getenv("HRN_S2_BLOCKS"))) : 512;   // 96-cout form off: those convolutions take the (48, 3) form
     bool disable_stem_mfma = getenv("HRN_DISABLE_STEM_MFMA") != nullptr;
     bool disable_head_mfma = getenv("HRN_DISABLE_HEAD_MFMA") != nullptr;
     bool direct_nr6 = getenv("HRN_DIRECT_NR6") ? atoi(getenv("HRN_DIRECT_NR6")) != 0 : true;
@@ -252,6 +281,14 @@ struct hrn_ctx {
         return all64 ? 4 : all48 ? 3 : 2;
     }
 
+    // output rows per tile of the stride-2 slab kernel: as many as one slab buffer holds ((2R + 1) virtual input rows of
+    // 2 * wop slots of 96 bytes)
+    static int s2_rows(int wop, int ho) {
+        const int vrows = kS2SlabBytes / (2 * wop * 96);
+        int r = (vrows - 1) / 2;
+        return r > ho ? ho : r;
+    }
+
     int add_conv(const std::string &conv, const std::string &bn, int in_t, int cout, int k, int stride, int relu,
                  int res_t = -1, bool emit = true, int nr_override = 0, int up = 0, int up_out_t = -1) {
         const Tensor ti = tensors[in_t];  // by value: new_tensor() below may reallocate `tensors`
@@ -287,6 +324,9 @@ struct hrn_ctx {
             op.slices = op.cin / lds_ks, op.ntiles = cout / (16 * lds_nrb), op.nch = (9 * lds_ks + 31) / 32;
             op.kpad = op.nch * 32 * op.slices;
         }
+        if (dtype == HRN_BF16 && k == 3 && stride == 2 && op.cin == 48 && cout % 48 == 0 && !up && !disable_s2 && op.algo == 0 &&
+            s2_rows(ow + 1, oh) >= 1)
+            op.s2 = true;
         convs.push_back(op);
         if (emit) emit_convs({(int)convs.size() - 1});
         return op.out_t;
@@ -297,34 +337,70 @@ struct hrn_ctx {
 
     // emit a set of mutually independent convolutions: one grouped launch when all of them run on the
     // LDS-staged kernel, individual launches otherwise
-    void emit_convs(const std::vector<int> &idx) {
-        std::vector<int> lds;
-        std::vector<std::vector<int>> dsets;  // generic kernel: one launch per cout-tile width
+    // convolutions on the generic kernel -> launches appended to `dst`: one grouped launch per cout-tile width
+    void emit_direct(const std::vector<int> &idx, std::vector<Op> &dst) {
+        std::vector<std::vector<int>> dsets;
         for (int i : idx) {
-            if (convs[i].algo == 1) {
-                lds.push_back(i);
-            } else if (convs[i].algo == 0 && !disable_dgroup) {
-                bool placed = false;
-                for (auto &set : dsets)
-                    if (convs[set[0]].nr == convs[i].nr && set.size() < 255) {
-                        set.push_back(i);
-                        placed = true;
-                        break;
-                    }
-                if (!placed) dsets.push_back({i});
-            } else {
-                ops.push_back({OP_CONV, i});
+            if (disable_dgroup) {
+                dst.push_back({OP_CONV, i});
+                continue;
             }
+            bool placed = false;
+            for (auto &set : dsets)
+                if (convs[set[0]].nr == convs[i].nr && set.size() < 255) {
+                    set.push_back(i);
+                    placed = true;
+                    break;
+                }
+            if (!placed) dsets.push_back({i});
         }
         for (auto &set : dsets) {
             if (set.size() == 1) {
-                ops.push_back({OP_CONV, set[0]});
+                dst.push_back({OP_CONV, set[0]});
                 continue;
             }
             DirectGroup g;
             g.conv_idx = set, g.nr = convs[set[0]].nr;
             dgroups.push_back(g);
-            ops.push_back({OP_CONV_GROUP, (int)dgroups.size() - 1});
+            dst.push_back({OP_CONV_GROUP, (int)dgroups.size() - 1});
+        }
+    }
+
+    void emit_convs(const std::vector<int> &idx) {
+        std::vector<int> lds, direct, s2;
+        for (int i : idx) {
+            if (convs[i].algo == 1)
+                lds.push_back(i);
+            else if (convs[i].s2)
+                s2.push_back(i);
+            else
+                direct.push_back(i);
+        }
+        emit_direct(direct, ops);
+        if (!s2.empty()) {
+            // stride-2 slab kernel: one problem per input tensor (at most 8 parts of 48 couts each), all of them one launch
+            S2Group g;
+            g.conv_idx = s2;
+            for (int i : s2) {
+                const ConvOp &cv = convs[i];
+                for (int t = 0; t < cv.cout / 48; ++t) {
+                    S2Group::Prob *pr = nullptr;
+                    for (auto &q : g.probs)
+                        if (q.in_t == cv.in_t && (int)q.parts.size() < kS2MaxParts) pr = &q;
+                    if (!pr) {
+                        g.probs.push_back(S2Group::Prob());
+                        pr = &g.probs.back();
+                        pr->in_t = cv.in_t;
+                        const Tensor &to = tensors[cv.out_t];
+                        pr->rows = s2_rows(to.wp, to.h);
+                        pr->tiles_per_image = (to.h + pr->rows - 1) / pr->rows;
+                    }
+                    pr->parts.push_back({i, t});
+                }
+            }
+            emit_direct(s2, g.fallback);
+            s2groups.push_back(g);
+            ops.push_back({OP_S2_GROUP, (int)s2groups.size() - 1});
         }
         if (lds.empty()) return;
         std::vector<std::vector<int>> sets;  // one launch per (KS, NRB) configuration
@@ -619,6 +695,9 @@ struct hrn_ctx {
                 case OP_CONV_GROUP:
                     for (int ci : dgroups[op.idx].conv_idx) add(convs[ci].conv, convs[ci].out_t, (int)oi, ci);
                     break;
+                case OP_S2_GROUP:
+                    for (int ci : s2groups[op.idx].conv_idx) add(convs[ci].conv, convs[ci].out_t, (int)oi, ci);
+                    break;
                 case OP_CHAIN:  // (the projection shortcut folded into the chain kernel is never written)
                     add(convs[chains[op.idx].conv3].conv, convs[chains[op.idx].conv3].out_t, (int)oi, chains[op.idx].conv3);
                     add(convs[chains[op.idx].conv1].conv, convs[chains[op.idx].conv1].out_t, (int)oi, chains[op.idx].conv1);
@@ -642,6 +721,11 @@ struct hrn_ctx {
             off = align_up(off + cv.w_bytes, 256);
             cv.b_off = off;
             off = align_up(off + cv.cout * 4, 256);
+            if (cv.s2) {  // the (48, 3) LDS image for the slab kernel: [cout tile][14 chunks][3 frags][64 lanes][16 B]
+                cv.w2_off = off;
+                cv.w2_bytes = (int64_t)(cv.cout / 48) * 14 * 3 * 1024;
+                off = align_up(off + cv.w2_bytes, 256);
+            }
         }
         head_w_off = off, off = align_up(off + (int64_t)joints * head_c * 4, 256);
         head_b_off = off, off = align_up(off + joints * 4, 256);
@@ -667,6 +751,7 @@ struct hrn_ctx {
         workspace_bytes += part * 8;
         if (plan_only) {
             index_groups();
+            index_s2groups();
             blob = (char *)calloc(1, (size_t)blob_bytes);
             return blob != nullptr;
         }
@@ -677,7 +762,7 @@ struct hrn_ctx {
         }
         if (!hip_ok(hipMalloc((void **)&blob, (size_t)blob_bytes), "hipMalloc(weights)")) return false;
         if (!hip_ok(hipMemset(blob, 0, (size_t)blob_bytes), "hipMemset(weights)")) return false;
-        if (!setup_groups() || !setup_dgroups()) return false;
+        if (!setup_groups() || !setup_dgroups() || !setup_s2groups()) return false;
         if (!hip_ok(hipMalloc((void **)&part_val, (size_t)part * 4), "hipMalloc(part_val)")) return false;
         if (!hip_ok(hipMalloc((void **)&part_idx, (size_t)part * 4), "hipMalloc(part_idx)")) return false;
         return hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
@@ -877,6 +962,92 @@ struct hrn_ctx {
         return true;
     }
 
+    // ---- stride-2 slab kernel: descriptors (fixed at create) and block maps (per micro-batch size)
+    size_t index_s2groups() {
+        size_t n = 0;
+        for (auto &g : s2groups) g.prob_first = (int)n, n += g.probs.size();
+        return n;
+    }
+    long s2_tiles(const S2Group &g, int nb) const {
+        long t = 0;
+        for (auto &pr : g.probs) t += (long)nb * pr.tiles_per_image;
+        return t;
+    }
+    // the slab kernel runs when the launch has a tile for every CU; smaller calls take the generic kernel (bit-identical)
+    bool s2_active(const S2Group &g, int nb) const { return s2_tiles(g, nb) >= s2_min_tiles; }
+    // Block map: every block walks a run of consecutive tiles of one problem (weights loaded once per block); run lengths are
+    // chosen so that blocks of all problems cost about the same and the launch has ~s2_target_blocks of them, costliest first.
+    int s2_blocks(const S2Group &g, int nb, std::vector<int2> *out) const {
+        struct Ent {
+            double key;
+            int2 v;
+        };
+        std::vector<double> cost(g.probs.size());
+        double total = 0;
+        for (size_t k = 0; k < g.probs.size(); ++k) {
+            const S2Group::Prob &pr = g.probs[k];
+            const Tensor &to = tensors[convs[pr.parts[0].first].out_t];
+            const int frags = (pr.rows * to.wp + 15) / 16;
+            const int wm = 8 / (int)pr.parts.size() ? 8 / (int)pr.parts.size() : 1;
+            cost[k] = (double)((frags + wm - 1) / wm) * 14 * 3 + 60;   // MFMAs of the busiest wave + per-tile overhead
+            total += cost[k] * nb * pr.tiles_per_image;
+        }
+        const double per_block = total / s2_target_blocks;
+        std::vector<Ent> ents;
+        for (size_t k = 0; k < g.probs.size(); ++k) {
+            const S2Group::Prob &pr = g.probs[k];
+            const int tiles = nb * pr.tiles_per_image;
+            int run = (int)(per_block / cost[k] + 0.5);
+            run = run < 1 ? 1 : run > 64 ? 64 : run;
+            for (int t0 = 0; t0 < tiles; t0 += run) {
+                const int cnt = tiles - t0 < run ? tiles - t0 : run;
+                ents.push_back({-(cnt * cost[k]) + 1e-9 * t0, int2{(int)k | (cnt << 8), t0}});
+            }
+        }
+        std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
+        if (out) {
+            out->resize(ents.size());
+            for (size_t i = 0; i < ents.size(); ++i) (*out)[i] = ents[i].v;
+        }
+        return (int)ents.size();
+    }
+
+    bool setup_s2groups() {
+        const size_t nprob = index_s2groups();
+        if (!nprob) return true;
+        std::vector<S2Problem> hp(nprob);
+        for (auto &g : s2groups) {
+            for (size_t k = 0; k < g.probs.size(); ++k) {
+                const S2Group::Prob &pr = g.probs[k];
+                const Tensor &ti = tensors[pr.in_t], &to = tensors[convs[pr.parts[0].first].out_t];
+                S2Problem &q = hp[g.prob_first + k];
+                memset(&q, 0, sizeof q);
+                q.in = row0(pr.in_t), q.in_wp = ti.wp, q.in_hpwp = ti.hpwp;
+                q.ho = to.h, q.wo = to.w, q.wop = to.wp, q.out_hpwp = to.hpwp;
+                q.rows = pr.rows, q.tiles_per_image = pr.tiles_per_image;
+                q.nparts = (int)pr.parts.size();
+                q.wm = 8 / q.nparts < 1 ? 1 : 8 / q.nparts;
+                fast_div(to.wp, &q.magic_wop, &q.shift_wop);
+                for (int i = 0; i < q.nparts; ++i) {
+                    const ConvOp &cv = convs[pr.parts[i].first];
+                    S2Part &pt = q.part[i];
+                    pt.w = blob + cv.w2_off + (int64_t)pr.parts[i].second * 14 * 3 * 1024;
+                    pt.bias = (const float *)(blob + cv.b_off);
+                    pt.out = row0(cv.out_t);
+                    pt.cout = cv.cout, pt.ch0 = pr.parts[i].second * 48, pt.relu = cv.relu;
+                }
+            }
+            g.map_capacity = 64;
+            for (auto &pr : g.probs) g.map_capacity += (int64_t)max_batch * pr.tiles_per_image;  // one tile per block bounds every split
+            for (MapSlot &sl : g.slot) {
+                if (!alloc_slot(sl, g.map_capacity, 0)) return false;
+                workspace_bytes += g.map_capacity * (int64_t)sizeof(int2);
+            }
+        }
+        if (!hip_ok(hipMalloc((void **)&s2probs_dev, nprob * sizeof(S2Problem)), "hipMalloc(s2 problems)")) return false;
+        return hip_ok(hipMemcpy(s2probs_dev, hp.data(), nprob * sizeof(S2Problem), hipMemcpyHostToDevice), "hipMemcpy(s2 problems)");
+    }
+
     bool alloc_slot(MapSlot &sl, int64_t capacity, size_t nargs) {
         if (!hip_ok(hipMalloc((void **)&sl.dev, (size_t)capacity * sizeof(int2)), "hipMalloc(blockmap)")) return false;
         if (!hip_ok(hipHostMalloc((void **)&sl.pin, (size_t)capacity * sizeof(int2), hipHostMallocDefault), "hipHostMalloc(blockmap)"))
@@ -992,6 +1163,9 @@ struct hrn_ctx {
             if (part_val) (void)hipFree(part_val);
             if (part_idx) (void)hipFree(part_idx);
             if (probs_dev) (void)hipFree(probs_dev);
+            if (s2probs_dev) (void)hipFree(s2probs_dev);
+            for (auto &g : s2groups)
+                for (MapSlot &sl : g.slot) free_slot(sl);
             for (auto &g : groups)
                 for (MapSlot &sl : g.slot) free_slot(sl);
             for (auto &g : dgroups)
@@ -1139,6 +1313,11 @@ struct hrn_ctx {
                 pack_conv_lds(cv, wf.data(), K, host.data() + cv.w_off);
             else
                 pack_conv(cv, wf.data(), K, host.data() + cv.w_off);
+            if (cv.s2) {
+                ConvOp img = cv;   // same folded weights in the (48, 3) slice-major form
+                img.ks = 48, img.nr = 3, img.slices = 1, img.ntiles = cv.cout / 48, img.nch = 14, img.n96 = false;
+                pack_conv_lds(img, wf.data(), K, host.data() + cv.w2_off);
+            }
             float *db = (float *)(host.data() + cv.b_off);
             for (int co = 0; co < cv.cout; ++co) db[co] = (float)shift[co];
         }
@@ -1236,157 +1415,186 @@ struct hrn_ctx {
                   hipStream_t s, Timing *tm, int flip = 0, const TapReq *tap = nullptr) {
         if (tm && !hip_ok(hipEventRecord(tm->ev[0], s), "hipEventRecord")) return false;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
-            const Op &op = ops[oi];
-            hipError_t e = hipSuccess;
             // every other launch walks its tensors backwards: it starts on what its producer wrote last, i.e. on the
             // part most likely still in the Infinity Cache (256 MB; a 256-crop tensor is up to 0.9 GB)
             const bool rev = alternate && (oi & 1);
-            switch (op.kind) {
-                case OP_STEM: {
-                    const Tensor &t = tensors[stem_out_t];
-                    StemArgs a;
-                    a.images = images, a.out = row0(stem_out_t);
-                    a.w = (const float *)(blob + stem_w_off), a.bias = (const float *)(blob + stem_b_off);
-                    a.wp = (dtype == HRN_BF16 && !disable_stem_mfma) ? (const void *)(blob + stem_wp_off) : nullptr;
-                    a.n = nb, a.H = H, a.W = W;
-                    a.out_h = t.h, a.out_w = t.w, a.out_wp = t.wp, a.out_hpwp = t.hpwp;
-                    a.flip = flip;
-                    e = launch_stem(dtype, a, s);
-                    break;
-                }
-                case OP_STEM7: {
-                    const Tensor &t = tensors[stem_out_t];
-                    Stem7Args a;
-                    a.images = images, a.out = row0(stem_out_t);
-                    a.w = (const float *)(blob + stem_w_off), a.bias = (const float *)(blob + stem_b_off);
-                    a.wp = (dtype == HRN_BF16 && !disable_stem_mfma) ? (const void *)(blob + stem_wp_off) : nullptr;
-                    a.n = nb, a.H = H, a.W = W;
-                    a.out_h = t.h, a.out_w = t.w, a.out_wp = t.wp, a.out_hpwp = t.hpwp;
-                    a.flip = flip;
-                    e = launch_stem7(dtype, a, s);
-                    break;
-                }
-                case OP_MAXPOOL: {
-                    const Tensor &ti = tensors[pool_in_t], &to = tensors[pool_out_t];
-                    PoolArgs a;
-                    a.in = row0(pool_in_t), a.out = row0(pool_out_t);
-                    a.c = to.c, a.n = nb, a.in_wp = ti.wp, a.in_hpwp = ti.hpwp;
-                    a.out_h = to.h, a.out_w = to.w, a.out_wp = to.wp, a.out_hpwp = to.hpwp;
-                    e = launch_maxpool(dtype, a, s);
-                    break;
-                }
-                case OP_CONV: {
-                    const ConvOp &cv = convs[op.idx];
-                    const ConvArgs a = conv_args(cv, nb, rev);
-                    e = launch_conv(dtype, a, cv.nr, s);
-                    break;
-                }
-                case OP_CONV3_GROUP: {
-                    Conv3Group &g = groups[op.idx];
-                    bool hit;
-                    MapSlot *sl = find_slot(g.slot, nb, &hit);
-                    if (!hit) {  // block map depends on the micro-batch size: build it once per size (kMapSlots sizes kept)
-                        sl->nblocks = group_blocks(g, nb, &g.map_host, rev);
-                        memcpy(sl->pin, g.map_host.data(), (size_t)sl->nblocks * sizeof(int2));
-                        e = hipMemcpyAsync(sl->dev, sl->pin, (size_t)sl->nblocks * sizeof(int2), hipMemcpyHostToDevice, s);
-                        if (e == hipSuccess) e = hipEventRecord(sl->landed, s);
-                        if (e != hipSuccess) break;
-                        sl->nb = nb;
-                        ++map_builds;
-                    }
-                    e = launch_conv3x3_lds(probs_dev + g.prob_first, sl->dev, sl->nblocks, nb, convs[g.conv_idx[0]].ks,
-                                           convs[g.conv_idx[0]].nr, s);
-                    break;
-                }
-                case OP_CONV_GROUP: {
-                    DirectGroup &g = dgroups[op.idx];
-                    bool hit;
-                    MapSlot *sl = find_slot(g.slot, nb, &hit);
-                    if (!hit) {  // descriptors (row counts) and block map depend on the micro-batch size
-                        for (size_t k = 0; k < g.conv_idx.size(); ++k) sl->args_pin[k] = conv_args(convs[g.conv_idx[k]], nb, rev);
-                        sl->mr = 4;  // shorter M tiles for small launches: fill the chip, shorten the serial K loop per block
-                        while (sl->mr > 1 && direct_group_blocks(g, nb, nullptr, sl->mr) < 512) sl->mr >>= 1;
-                        sl->nblocks = direct_group_blocks(g, nb, &g.map_host, sl->mr);
-                        memcpy(sl->pin, g.map_host.data(), (size_t)sl->nblocks * sizeof(int2));
-                        e = hipMemcpyAsync(sl->args_dev, sl->args_pin, g.conv_idx.size() * sizeof(ConvArgs), hipMemcpyHostToDevice, s);
-                        if (e == hipSuccess)
-                            e = hipMemcpyAsync(sl->dev, sl->pin, (size_t)sl->nblocks * sizeof(int2), hipMemcpyHostToDevice, s);
-                        if (e == hipSuccess) e = hipEventRecord(sl->landed, s);
-                        if (e != hipSuccess) break;
-                        sl->nb = nb;
-                        ++map_builds;
-                    }
-                    e = launch_conv_group(dtype, sl->args_dev, sl->dev, sl->nblocks, g.nr, sl->mr, direct_wlds && dtype == 1, s);
-                    break;
-                }
-                case OP_CHAIN: {
-                    const Chain &ch = chains[op.idx];
-                    const ConvOp &c3 = convs[ch.conv3], &c1 = convs[ch.conv1];
-                    const Tensor &to = tensors[c3.out_t];
-                    ChainArgs a;
-                    a.in = row0(c3.in_t), a.res = row0(c3.res_t), a.out_y = row0(c3.out_t), a.out_t = row0(c1.out_t);
-                    a.w3 = blob + c3.w_off, a.b3 = (const float *)(blob + c3.b_off);
-                    a.w1 = blob + c1.w_off, a.b1 = (const float *)(blob + c1.b_off);
-                    a.x = nullptr, a.wds = nullptr, a.bds = nullptr;
-                    if (ch.ds >= 0) {
-                        const ConvOp &cd = convs[ch.ds];
-                        a.x = row0(cd.in_t), a.wds = blob + cd.w_off, a.bds = (const float *)(blob + cd.b_off);
-                        a.res = nullptr;
-                    }
-                    a.m = nb * to.hpwp, a.h = to.h, a.w = to.w, a.wp = to.wp, a.hpwp = to.hpwp, a.rev = rev;
-                    e = launch_bottleneck_chain(a, s);
-                    break;
-                }
-                case OP_FUSE: {
-                    const FuseOp &f = fuses[op.idx];
-                    const Tensor &to = tensors[f.out_t];
-                    FuseArgs a;
-                    a.nterms = f.nterms;
-                    for (int i = 0; i < f.nterms; ++i) {
-                        const Tensor &tt = tensors[f.term_t[i]];
-                        a.t[i].ptr = row0(f.term_t[i]), a.t[i].shift = f.shift[i];
-                        a.t[i].wp = tt.wp, a.t[i].hpwp = tt.hpwp;
-                    }
-                    for (int i = f.nterms; i < 4; ++i) a.t[i] = FuseTerm{nullptr, 0, 0, 0};
-                    a.out = row0(f.out_t), a.c = to.c, a.h = to.h, a.w = to.w, a.wp = to.wp, a.hpwp = to.hpwp;
-                    a.m = nb * to.hpwp, a.rev = rev;
-                    e = launch_fuse(dtype, a, s);
-                    break;
-                }
-                case OP_HEAD: {
-                    const Tensor &t = tensors[head_in_t];
-                    HeadArgs a;
-                    a.in = row0(head_in_t);
-                    a.wgt = (const float *)(blob + head_w_off), a.bias = (const float *)(blob + head_b_off);
-                    a.wimg = (dtype == HRN_BF16 && !disable_head_mfma) ? (const void *)(blob + head_wp_off) : nullptr;
-                    a.heatmaps = heatmaps, a.part_val = part_val, a.part_idx = part_idx;
-                    a.n = nb, a.c = t.c, a.joints = joints, a.h = t.h, a.w = t.w, a.wp = t.wp, a.hpwp = t.hpwp;
-                    a.slabs = head_slabs, a.slab_px = head_slab_px;
-                    e = launch_head(dtype, a, s);
-                    break;
-                }
-                case OP_DECODE: {
-                    if (!pts) break;
-                    const Tensor &t = tensors[head_in_t];
-                    DecodeArgs a;
-                    a.part_val = part_val, a.part_idx = part_idx, a.boxes = boxes;
-                    a.box_is_float = box_dtype == HRN_BOX_F32, a.pts = pts;
-                    a.n = nb, a.joints = joints, a.h = t.h, a.w = t.w, a.slabs = head_slabs;
-                    e = launch_decode(a, s);
-                    break;
-                }
-            }
+            const hipError_t e = exec_op(ops[oi], rev, images, nb, boxes, box_dtype, pts, heatmaps, s, flip);
             if (!hip_ok(e, "kernel launch")) return false;
             if (tap && tap->op == (int)oi) {  // debug tap: the tensor this launch completed, as (ncrops, C, H, W) fp32
                 const Tensor &t = tensors[tap->tensor];
                 TapArgs a;
                 a.in = row0(tap->tensor), a.dst = tap->dst;
-                a.c = t.c, a.h = t.h, a.w = t.w, a.wp = t.wp, a.hpwp = t.hpwp, a.crop0 = tap->crop0, a.ncrops = tap->ncrops, a.crop_step = tap->crop_step;
+                a.c = t.c, a.h = t.h, a.w = t.w, a.wp = t.wp, a.hpwp = t.hpwp;
+                a.crop0 = tap->crop0, a.ncrops = tap->ncrops, a.crop_step = tap->crop_step;
                 if (!hip_ok(launch_tap(dtype, a, s), "tap launch")) return false;
             }
             if (tm && !hip_ok(hipEventRecord(tm->ev[oi + 1], s), "hipEventRecord")) return false;
         }
         return true;
+    }
+
+    hipError_t exec_op(const Op &op, bool rev, const float *images, int nb, const void *boxes, int box_dtype, float *pts,
+                       float *heatmaps, hipStream_t s, int flip) {
+        hipError_t e = hipSuccess;
+        switch (op.kind) {
+        case OP_STEM: {
+            const Tensor &t = tensors[stem_out_t];
+            StemArgs a;
+            a.images = images, a.out = row0(stem_out_t);
+            a.w = (const float *)(blob + stem_w_off), a.bias = (const float *)(blob + stem_b_off);
+            a.wp = (dtype == HRN_BF16 && !disable_stem_mfma) ? (const void *)(blob + stem_wp_off) : nullptr;
+            a.n = nb, a.H = H, a.W = W;
+            a.out_h = t.h, a.out_w = t.w, a.out_wp = t.wp, a.out_hpwp = t.hpwp;
+            a.flip = flip;
+            e = launch_stem(dtype, a, s);
+            break;
+        }
+        case OP_STEM7: {
+            const Tensor &t = tensors[stem_out_t];
+            Stem7Args a;
+            a.images = images, a.out = row0(stem_out_t);
+            a.w = (const float *)(blob + stem_w_off), a.bias = (const float *)(blob + stem_b_off);
+            a.wp = (dtype == HRN_BF16 && !disable_stem_mfma) ? (const void *)(blob + stem_wp_off) : nullptr;
+            a.n = nb, a.H = H, a.W = W;
+            a.out_h = t.h, a.out_w = t.w, a.out_wp = t.wp, a.out_hpwp = t.hpwp;
+            a.flip = flip;
+            e = launch_stem7(dtype, a, s);
+            break;
+        }
+        case OP_MAXPOOL: {
+            const Tensor &ti = tensors[pool_in_t], &to = tensors[pool_out_t];
+            PoolArgs a;
+            a.in = row0(pool_in_t), a.out = row0(pool_out_t);
+            a.c = to.c, a.n = nb, a.in_wp = ti.wp, a.in_hpwp = ti.hpwp;
+            a.out_h = to.h, a.out_w = to.w, a.out_wp = to.wp, a.out_hpwp = to.hpwp;
+            e = launch_maxpool(dtype, a, s);
+            break;
+        }
+        case OP_CONV: {
+            const ConvOp &cv = convs[op.idx];
+            const ConvArgs a = conv_args(cv, nb, rev);
+            e = launch_conv(dtype, a, cv.nr, s);
+            break;
+        }
+        case OP_CONV3_GROUP: {
+            Conv3Group &g = groups[op.idx];
+            bool hit;
+            MapSlot *sl = find_slot(g.slot, nb, &hit);
+            if (!hit) {  // block map depends on the micro-batch size: build it once per size (kMapSlots sizes kept)
+                sl->nblocks = group_blocks(g, nb, &g.map_host, rev);
+                memcpy(sl->pin, g.map_host.data(), (size_t)sl->nblocks * sizeof(int2));
+                e = hipMemcpyAsync(sl->dev, sl->pin, (size_t)sl->nblocks * sizeof(int2), hipMemcpyHostToDevice, s);
+                if (e == hipSuccess) e = hipEventRecord(sl->landed, s);
+                if (e != hipSuccess) break;
+                sl->nb = nb;
+                ++map_builds;
+            }
+            e = launch_conv3x3_lds(probs_dev + g.prob_first, sl->dev, sl->nblocks, nb, convs[g.conv_idx[0]].ks,
+                                   convs[g.conv_idx[0]].nr, s);
+            break;
+        }
+        case OP_CONV_GROUP: {
+            DirectGroup &g = dgroups[op.idx];
+            bool hit;
+            MapSlot *sl = find_slot(g.slot, nb, &hit);
+            if (!hit) {  // descriptors (row counts) and block map depend on the micro-batch size
+                for (size_t k = 0; k < g.conv_idx.size(); ++k) sl->args_pin[k] = conv_args(convs[g.conv_idx[k]], nb, rev);
+                sl->mr = 4;  // shorter M tiles for small launches: fill the chip, shorten the serial K loop per block
+                while (sl->mr > 1 && direct_group_blocks(g, nb, nullptr, sl->mr) < 512) sl->mr >>= 1;
+                sl->nblocks = direct_group_blocks(g, nb, &g.map_host, sl->mr);
+                memcpy(sl->pin, g.map_host.data(), (size_t)sl->nblocks * sizeof(int2));
+                e = hipMemcpyAsync(sl->args_dev, sl->args_pin, g.conv_idx.size() * sizeof(ConvArgs), hipMemcpyHostToDevice, s);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(sl->dev, sl->pin, (size_t)sl->nblocks * sizeof(int2), hipMemcpyHostToDevice, s);
+                if (e == hipSuccess) e = hipEventRecord(sl->landed, s);
+                if (e != hipSuccess) break;
+                sl->nb = nb;
+                ++map_builds;
+            }
+            e = launch_conv_group(dtype, sl->args_dev, sl->dev, sl->nblocks, g.nr, sl->mr, direct_wlds && dtype == 1, s);
+            break;
+        }
+        case OP_S2_GROUP: {
+            S2Group &g = s2groups[op.idx];
+            if (!s2_active(g, nb)) {  // too few tiles for the slab kernel: the same convolutions on the generic kernel
+                for (const Op &f : g.fallback) {
+                    e = exec_op(f, rev, images, nb, boxes, box_dtype, pts, heatmaps, s, flip);
+                    if (e != hipSuccess) break;
+                }
+                break;
+            }
+            bool hit;
+            MapSlot *sl = find_slot(g.slot, nb, &hit);
+            if (!hit) {
+                sl->nblocks = s2_blocks(g, nb, &g.map_host);
+                memcpy(sl->pin, g.map_host.data(), (size_t)sl->nblocks * sizeof(int2));
+                e = hipMemcpyAsync(sl->dev, sl->pin, (size_t)sl->nblocks * sizeof(int2), hipMemcpyHostToDevice, s);
+                if (e == hipSuccess) e = hipEventRecord(sl->landed, s);
+                if (e != hipSuccess) break;
+                sl->nb = nb;
+                ++map_builds;
+            }
+            e = launch_conv_s2(s2probs_dev + g.prob_first, sl->dev, sl->nblocks, s);
+            break;
+        }
+        case OP_CHAIN: {
+            const Chain &ch = chains[op.idx];
+            const ConvOp &c3 = convs[ch.conv3], &c1 = convs[ch.conv1];
+            const Tensor &to = tensors[c3.out_t];
+            ChainArgs a;
+            a.in = row0(c3.in_t), a.res = row0(c3.res_t), a.out_y = row0(c3.out_t), a.out_t = row0(c1.out_t);
+            a.w3 = blob + c3.w_off, a.b3 = (const float *)(blob + c3.b_off);
+            a.w1 = blob + c1.w_off, a.b1 = (const float *)(blob + c1.b_off);
+            a.x = nullptr, a.wds = nullptr, a.bds = nullptr;
+            if (ch.ds >= 0) {
+                const ConvOp &cd = convs[ch.ds];
+                a.x = row0(cd.in_t), a.wds = blob + cd.w_off, a.bds = (const float *)(blob + cd.b_off);
+                a.res = nullptr;
+            }
+            a.m = nb * to.hpwp, a.h = to.h, a.w = to.w, a.wp = to.wp, a.hpwp = to.hpwp, a.rev = rev;
+            e = launch_bottleneck_chain(a, s);
+            break;
+        }
+        case OP_FUSE: {
+            const FuseOp &f = fuses[op.idx];
+            const Tensor &to = tensors[f.out_t];
+            FuseArgs a;
+            a.nterms = f.nterms;
+            for (int i = 0; i < f.nterms; ++i) {
+                const Tensor &tt = tensors[f.term_t[i]];
+                a.t[i].ptr = row0(f.term_t[i]), a.t[i].shift = f.shift[i];
+                a.t[i].wp = tt.wp, a.t[i].hpwp = tt.hpwp;
+            }
+            for (int i = f.nterms; i < 4; ++i) a.t[i] = FuseTerm{nullptr, 0, 0, 0};
+            a.out = row0(f.out_t), a.c = to.c, a.h = to.h, a.w = to.w, a.wp = to.wp, a.hpwp = to.hpwp;
+            a.m = nb * to.hpwp, a.rev = rev;
+            e = launch_fuse(dtype, a, s);
+            break;
+        }
+        case OP_HEAD: {
+            const Tensor &t = tensors[head_in_t];
+            HeadArgs a;
+            a.in = row0(head_in_t);
+            a.wgt = (const float *)(blob + head_w_off), a.bias = (const float *)(blob + head_b_off);
+            a.wimg = (dtype == HRN_BF16 && !disable_head_mfma) ? (const void *)(blob + head_wp_off) : nullptr;
+            a.heatmaps = heatmaps, a.part_val = part_val, a.part_idx = part_idx;
+            a.n = nb, a.c = t.c, a.joints = joints, a.h = t.h, a.w = t.w, a.wp = t.wp, a.hpwp = t.hpwp;
+            a.slabs = head_slabs, a.slab_px = head_slab_px;
+            e = launch_head(dtype, a, s);
+            break;
+        }
+        case OP_DECODE: {
+            if (!pts) break;
+            const Tensor &t = tensors[head_in_t];
+            DecodeArgs a;
+            a.part_val = part_val, a.part_idx = part_idx, a.boxes = boxes;
+            a.box_is_float = box_dtype == HRN_BOX_F32, a.pts = pts;
+            a.n = nb, a.joints = joints, a.h = t.h, a.w = t.w, a.slabs = head_slabs;
+            e = launch_decode(a, s);
+            break;
+        }
+    }
+        return e;
     }
 
     bool check_forward_args(const void *images, int n, const void *boxes, float *pts, float *heatmaps) {
@@ -1791,7 +1999,7 @@ int hrn_get_conv_info(hrn_handle h, int index, hrn_conv_info *out) {
     out->has_residual = cv.res_t >= 0;
     out->in_h = h->tensors[cv.in_t].h, out->in_w = h->tensors[cv.in_t].w;
     out->out_h = h->tensors[cv.out_t].h, out->out_w = h->tensors[cv.out_t].w;
-    out->kpad = cv.kpad, out->nr = cv.nr, out->algo = cv.fuse_with >= 0 || cv.fused_away ? 2 : cv.n96 ? 3 : cv.algo, out->ks = cv.ks;
+    out->kpad = cv.kpad, out->nr = cv.nr, out->algo = cv.fuse_with >= 0 || cv.fused_away ? 2 : cv.n96 ? 3 : cv.s2 ? 4 : cv.algo, out->ks = cv.ks;
     out->w_offset = cv.w_off, out->w_bytes = cv.w_bytes, out->b_offset = cv.b_off;
     out->flops = cv.flops;
     return 0;
@@ -1849,6 +2057,27 @@ int hrn_plan_direct_map(hrn_handle h, int group, int n, int32_t *blocks, int cap
     return nblocks;
 }
 
+int hrn_plan_s2_map(hrn_handle h, int group, int n, int32_t *blocks, int capacity, int32_t *parts, int part_capacity, int32_t *active) {
+    if (!h || n <= 0 || n > h->max_batch) return -1;
+    if (group < 0 || group >= (int)h->s2groups.size()) return -1;
+    const S2Group &g = h->s2groups[group];
+    std::vector<int2> map;
+    const int nblocks = h->s2_blocks(g, n, &map);
+    for (int i = 0; i < nblocks && i < capacity; ++i)
+        blocks[(size_t)i * 3] = map[i].x & 0xff, blocks[(size_t)i * 3 + 1] = map[i].x >> 8, blocks[(size_t)i * 3 + 2] = map[i].y;
+    int np = 0;  // per part: problem, convolution, 48-cout tile, rows per tile, tiles per image
+    for (size_t k = 0; k < g.probs.size(); ++k)
+        for (auto &pt : g.probs[k].parts) {
+            if (np < part_capacity) {
+                int32_t *o = parts + (size_t)np * 5;
+                o[0] = (int32_t)k, o[1] = pt.first, o[2] = pt.second, o[3] = g.probs[k].rows, o[4] = g.probs[k].tiles_per_image;
+            }
+            ++np;
+        }
+    if (active) *active = h->s2_active(g, n) ? 1 : 0;
+    return nblocks | (np << 20);
+}
+
 int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms, int conv_ms_len, float *other_ms,
                      void *stream) {
     if (!h) return 1;
@@ -1897,6 +2126,12 @@ int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms
                 }
                 for (size_t k = 0; k < g.conv_idx.size(); ++k)
                     if (conv_ms && g.conv_idx[k] < conv_ms_len) conv_ms[g.conv_idx[k]] = (float)(ms * wgt[k] / tot);
+            } else if (op.kind == OP_S2_GROUP) {  // one launch (or its generic fallback): split by FLOPs
+                const S2Group &g = h->s2groups[op.idx];
+                double tot = 0;
+                for (int ci : g.conv_idx) tot += h->convs[ci].flops;
+                for (int ci : g.conv_idx)
+                    if (conv_ms && ci < conv_ms_len) conv_ms[ci] = (float)(ms * h->convs[ci].flops / tot);
             } else if (op.kind == OP_CHAIN) {  // two or three 1x1 convs of equal FLOPs
                 const hrn_ctx::Chain &ch = h->chains[op.idx];
                 const float share = ch.ds >= 0 ? ms / 3.f : ms * 0.5f;

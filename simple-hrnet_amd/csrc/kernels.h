@@ -62,6 +62,31 @@ int conv3x3_n96_ch64();           // output-channel permutation of the 96-cout f
 int conv3x3_lds_bbf_ok(int wp);  // the fused BasicBlock kernel fits this row pitch
 int conv3x3_lds_bm(int ks, int nrb, int wp);  // (32, 6) = the 96-cout form
 
+// Stride-2 slab kernel (conv_s2.hip): every 3x3 / stride-2 convolution with 48 input channels that reads ONE tensor at one
+// fuse level is a "part" (48 output channels each) of one problem; a block stages the input slab of `rows` output rows once
+// and its waves keep the parts' weights in registers.
+constexpr int kS2SlabBytes = 79872;   // one slab buffer: 832 slots of 96 bytes (two of them + the biases fill the 160 KiB)
+constexpr int kS2MaxParts = 8;
+struct S2Part {
+    const void *w;      // [14 chunks][3 frags][64 lanes][16 B]: the (48, 3) image of pack_conv_lds for this 48-cout tile
+    const float *bias;  // the convolution's folded bias (indexed with ch0 + c)
+    void *out;          // row 0 of the convolution's output tensor
+    int cout, ch0;      // channels per row of that tensor, first channel of this part
+    int relu, pad_;
+};
+struct S2Problem {
+    const void *in;     // row 0 of the input tensor (48 channels)
+    int in_wp, in_hpwp;
+    int ho, wo, wop, out_hpwp;   // output geometry (shared by all parts)
+    int rows;                    // output rows per tile
+    int tiles_per_image;         // ceil(ho / rows)
+    int nparts, wm;              // cout groups; waves per group = 8 / nparts (wave -> (group, share of the fragments))
+    unsigned magic_wop;          // x / wop == (x * magic) >> shift
+    int shift_wop;
+    S2Part part[kS2MaxParts];
+};
+hipError_t launch_conv_s2(const S2Problem *probs_dev, const void *map_dev, int nblocks, hipStream_t s);
+
 // layer1: conv3 (+shortcut, ReLU) of one Bottleneck and conv1 (+ReLU) of the next in one pass (bottleneck_chain.hip)
 struct ChainArgs {
     const void *in;        // conv2 output of block b: [rows][64]

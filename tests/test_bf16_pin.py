@@ -99,16 +99,33 @@ class Pinner:
         got = self.native(name) if got is None else got
         if got is None:
             return False
-        want, mag = self.emu.eval_node(name, self.inputs(name), magnitude=True)
+        ins = self.inputs(name)
+        emulated_input = any(self.native(i) is None for i in self.emu.inputs_of(name))
+        want, mag = self.emu.eval_node(name, ins, magnitude=True)
         got, want, mag = got.double(), want.double(), mag.double()
         d = (got - want).abs()
-        bound = ULP * torch.maximum(got.abs(), want.abs()) + NOISE * mag
+        fp32_out = name == self.emu.HEAD                      # heat-maps are not rounded: summation noise only
+        bound = NOISE * mag if fp32_out else ULP * torch.maximum(got.abs(), want.abs()) + NOISE * mag
         frac = float((d > 0).double().mean())
         over = d > bound
+        nover = int(over.sum())
         self.stats.append((name, float((d / bound.clamp_min(1e-30)).max()), frac))
-        assert not bool(over.any()), "%s: %d of %d elements beyond one bf16 ulp (worst %.3g x the bound; |d| max %.4g at |x| max %.4g); %.3f %% differ at all" % (
-            name, int(over.sum()), d.numel(), float((d / bound.clamp_min(1e-30)).max()), float(d.max()), float(want.abs().max()), 100 * frac)
-        assert frac <= MAX_DIFF_FRAC, "%s: %.2f %% of the elements differ from the emulation (allowed %.2f %%)" % (name, 100 * frac, 100 * MAX_DIFF_FRAC)
+        if nover and emulated_input:
+            # An input of this op never reaches HBM (conv1 of a fused BasicBlock, the projection shortcut inside the chain
+            # kernel): the engine rounded ITS value, the emulation rounded its own, and where those two roundings fell on
+            # different sides the difference (one ulp of the INTERMEDIATE, times a weight) is no defect of this op.  Such
+            # elements must be rare and stay within one ulp of the largest term.
+            loose = ULP * mag
+            assert nover <= max(4, int(2e-4 * d.numel())) and not bool((d > loose).any()), "%s: %d of %d elements beyond the bound (intermediate kept on-chip); worst %.3g" % (
+                name, nover, d.numel(), float(d.max()))
+            nover = 0
+        if nover:
+            idx = torch.nonzero(over)[:6]
+            where = "; ".join("%s got %.6g want %.6g sum|terms| %.4g" % (tuple(int(v) for v in ix), float(got[tuple(ix)]), float(want[tuple(ix)]),
+                                                                          float(mag[tuple(ix)])) for ix in idx)
+            raise AssertionError("%s: %d of %d elements beyond one bf16 ulp (worst %.3g x the bound; |d| max %.4g at |x| max %.4g); %.3f %% differ at all; first: %s" % (
+                name, nover, d.numel(), float((d / bound.clamp_min(1e-30)).max()), float(d.max()), float(want.abs().max()), 100 * frac, where))
+        assert fp32_out or frac <= MAX_DIFF_FRAC, "%s: %.2f %% of the elements differ from the emulation (allowed %.2f %%)" % (name, 100 * frac, 100 * MAX_DIFF_FRAC)
         return True
 
     def check_all(self, names=None):
