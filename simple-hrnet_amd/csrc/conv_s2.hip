@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
     const GLOBAL_AS S2Problem *pp = (const GLOBAL_AS S2Problem *)(probs + prob);
     // the descriptor's fields as scalars, once (a field read through a pointer is re-loaded after every "memory" clobber)
     const int in_wp = pp->in_wp, in_hpwp = pp->in_hpwp, Ho = pp->ho, Wo = pp->wo, Wop = pp->wop, out_hpwp = pp->out_hpwp;
-    const int R = pp->rows, tpi = pp->tiles_per_image, nparts = pp->nparts, WM = pp->wm;
+    const int R = pp->rows, tpi = pp->tiles_per_image, nparts = pp->nparts;
     const unsigned magic_wop = pp->magic_wop;
     const int shift_wop = pp->shift_wop;
     const GLOBAL_AS char *const in = (const GLOBAL_AS char *)pp->in;
@@ -67,40 +67,52 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
-    const int wn = wave / WM, wm = wave - wn * WM;       // cout group of this wave, its share of the pixel fragments
-    const bool active = wn < nparts;
-    const int part = active ? wn : 0;
+    // this wave's cout group and its share of a tile's pixel fragments: fragments f0, f0 + fs, ... (host: balanced per SIMD)
+    const int wpart = __builtin_amdgcn_readfirstlane((int)pp->wave_part[wave]);
+    const int wf0 = __builtin_amdgcn_readfirstlane((int)pp->wave_f0[wave]), wfs = __builtin_amdgcn_readfirstlane((int)pp->wave_fs[wave]);
+    const bool active = wpart < nparts;
+    const int part = active ? wpart : 0;
 
     char *const sbuf = smem_s2;
     float *const bias_lds = (float *)(smem_s2 + 2 * kS2SlabBytes);   // [8][48]
 
-    // ---- the slab of tile `t` -> buffer `b` (all 512 threads; wave-uniform piece predicate)
+    // ---- LDS-DMA of a slab, one 1-KiB piece (64 lanes x 16 bytes) per call; piece k of this wave = units k*512 + wave*64 ...
     const int slots_per_vrow = 2 * Wop;
-    auto issue_slab = [&](int t, int b) {
+    struct Slab {
+        const GLOBAL_AS char *src;
+        char *dst;
+        int units;
+    };
+    auto plan_slab = [&](int t, int b) {
         const int n = t / tpi, rg = t - n * tpi;
         const int h0 = rg * R;
         const int rt = Ho - h0 < R ? Ho - h0 : R;
-        const int units = (2 * rt + 1) * slots_per_vrow * UPR;
+        Slab sl;
+        sl.units = (2 * rt + 1) * slots_per_vrow * UPR;
         // first pixel of the slab: row 2*h0 - 1, column -1 of image n (guard rows / the previous image's pad row when h0 == 0)
         const long px0 = (long)n * in_hpwp + (long)(2 * h0 - 1) * in_wp - 1;
-        const GLOBAL_AS char *src = in + px0 * ROWB;
-        char *dst = sbuf + b * kS2SlabBytes;
-#pragma unroll
-        for (int k = 0; k < NSP; ++k) {
-            if (k * NT + wave * 64 < units) {   // wave-uniform
-                int u = k * NT + tid;
-                if (u >= units) u = units - 1;  // tail lanes re-read a valid unit (their LDS slots lie inside the buffer, unused)
-                const int slot = (int)(((unsigned)u * 43691u) >> 18);  // u / 6 for u < 2^15
-                const int piece = u - slot * UPR;
-                const int vrow = slot / slots_per_vrow, rem = slot - vrow * slots_per_vrow;
-                const int plane = rem >= Wop ? 1 : 0, j = rem - plane * Wop;
-                const int rel = (vrow * in_wp + 2 * j + plane) * ROWB + piece * 16;
-                glds16(src + rel, dst + (k * NT + wave * 64) * 16);
-            }
+        sl.src = in + px0 * ROWB;
+        sl.dst = sbuf + b * kS2SlabBytes;
+        return sl;
+    };
+    auto piece = [&](const Slab &sl, int k) {
+        if (k * NT + wave * 64 < sl.units) {   // wave-uniform
+            int u = k * NT + tid;
+            if (u >= sl.units) u = sl.units - 1;  // tail lanes re-read a valid unit (their LDS slots lie inside the buffer, unused)
+            const int slot = (int)(((unsigned)u * 43691u) >> 18);  // u / 6 for u < 2^15
+            const int pc = u - slot * UPR;
+            const int vrow = slot / slots_per_vrow, rem = slot - vrow * slots_per_vrow;
+            const int plane = rem >= Wop ? 1 : 0, j = rem - plane * Wop;
+            const int rel = (vrow * in_wp + 2 * j + plane) * ROWB + pc * 16;
+            glds16(sl.src + rel, sl.dst + (k * NT + wave * 64) * 16);
         }
     };
 
-    issue_slab(tile0, 0);
+    {
+        const Slab s0 = plan_slab(tile0, 0);
+#pragma unroll
+        for (int k = 0; k < NSP; ++k) piece(s0, k);
+    }
 
     // ---- this wave's weights: 14 chunks x 3 fragments, resident in registers; its bias -> LDS
     s16x8 wf[NCH][3];
@@ -117,6 +129,7 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
     }
     const int cout = pp->part[part].cout, ch0 = pp->part[part].ch0, relu = pp->part[part].relu;
     GLOBAL_AS unsigned short *const out = (GLOBAL_AS unsigned short *)pp->part[part].out;
+    const float lo = relu ? 0.f : -INFINITY;   // ReLU as one v_max with a wave-uniform floor
 
     // per-lane LDS byte offset of k-group g of chunk c relative to the lane's own pixel slot (row 2*rr, plane 0, j = wo)
     int xoff[NCH];
@@ -130,12 +143,26 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_s2;
 
+    int nlast = 0;   // stores this wave issued AFTER its last LDS-DMA piece of the previous iteration (they may stay in flight)
     for (int k = 0; k < ntile; ++k) {
         const int t = tile0 + k, b = k & 1;
-        // my pieces of this tile's slab have landed (and my stores of the previous tile have left)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // everybody's have; everybody is done reading the other buffer
-        if (k + 1 < ntile) issue_slab(t + 1, b ^ 1);
+        // my pieces of this tile's slab have landed.  vmcnt retires in order and counts stores: the youngest `nlast`
+        // operations are the previous tile's last stores, everything older (all LDS-DMA pieces) must be complete
+        if (nlast == 4)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (nlast == 2)
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // everybody's have; everybody is done reading the other buffer
+        // the next tile's slab goes out piece by piece under this tile's MFMAs (an LDS-DMA instruction costs its wave
+        // ~150 issue cycles; issued in one burst by all eight waves the block would compute nothing meanwhile)
+        Slab nx;
+        nx.units = 0, nx.src = in, nx.dst = sbuf;
+        if (k + 1 < ntile) nx = plan_slab(t + 1, b ^ 1);
+        int pk = 0;   // next piece to issue (wave-uniform)
+        nlast = 0;
 
         const int n = t / tpi, rg = t - n * tpi;
         const int h0 = rg * R;
@@ -144,9 +171,10 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
         const int mf = (npx + 15) >> 4;
         const long q0 = (long)n * out_hpwp + (long)h0 * Wop;   // flat output row of the tile's first pixel
         if (active) {
-            for (int f0 = wm; f0 < mf; f0 += 2 * WM) {
-                const int f1 = f0 + WM;
-                const bool two = f1 < mf;   // wave-uniform
+            for (int f0 = wf0; f0 < mf; f0 += 2 * wfs) {
+                const int f1 = f0 + wfs;
+                const bool two = f1 < mf;                 // wave-uniform
+                const bool last_pair = f0 + 2 * wfs >= mf;
                 int tp[2], wo[2];
                 unsigned xa[2];
 #pragma unroll
@@ -188,34 +216,50 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
                                                                             __builtin_bit_cast(bf16x8, xf[cur][1]), acc[1][j], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if ((c & 1) && pk < NSP) {   // one LDS-DMA piece every other chunk
+                        piece(nx, pk);
+                        ++pk;
+                    }
                 }
 #undef S2_READ
+                if (last_pair) {  // whatever is left of the next slab goes out BEFORE this wave's last stores (counted wait above)
+                    for (; pk < NSP; ++pk) piece(nx, pk);
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);   // the stores below stay below: they are what the counted wait leaves in flight
+                }
                 // ---- epilogue: + bias, ReLU, zero at the pad column; a lane owns 12 contiguous channels of one pixel
                 const float *bl = bias_lds + part * 48 + g * 12;
                 const f32x4 b0 = *(const f32x4 *)(bl), b1 = *(const f32x4 *)(bl + 4), b2 = *(const f32x4 *)(bl + 8);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     if (i == 1 && !two) break;
-                    if (tp[i] >= npx) continue;
-                    const bool ok = wo[i] < Wo;
-                    float v[12];
+                    if (tp[i] < npx) {
+                        const float hi = wo[i] < Wo ? INFINITY : 0.f;   // pad column: clamp to [0, 0]
+                        const float lo_i = wo[i] < Wo ? lo : 0.f;
+                        float v[12];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = acc[i][0][r] + b0[r];
-                        v[4 + r] = acc[i][1][r] + b1[r];
-                        v[8 + r] = acc[i][2][r] + b2[r];
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = acc[i][0][r] + b0[r];
+                            v[4 + r] = acc[i][1][r] + b1[r];
+                            v[8 + r] = acc[i][2][r] + b2[r];
+                        }
+                        unsigned pk2[6];
 #pragma unroll
-                    for (int r = 0; r < 12; ++r) {
-                        if (relu) v[r] = fmaxf(v[r], 0.f);
-                        if (!ok) v[r] = 0.f;
+                        for (int r = 0; r < 6; ++r) {
+                            float a0, a1;
+                            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(a0) : "v"(v[2 * r]), "v"(lo_i), "v"(hi));
+                            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(a1) : "v"(v[2 * r + 1]), "v"(lo_i), "v"(hi));
+                            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk2[r]) : "v"(a0), "v"(a1));
+                        }
+                        GLOBAL_AS unsigned short *o = out + (size_t)(q0 + tp[i]) * cout + ch0 + g * 12;
+                        *(GLOBAL_AS u32x4 *)o = u32x4{pk2[0], pk2[1], pk2[2], pk2[3]};
+                        *(GLOBAL_AS u32x2 *)(o + 8) = u32x2{pk2[4], pk2[5]};
                     }
-                    GLOBAL_AS unsigned short *o = out + (size_t)(q0 + tp[i]) * cout + ch0 + g * 12;
-                    *(GLOBAL_AS u32x4 *)o = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-                    *(GLOBAL_AS u32x2 *)(o + 8) = u32x2{pack2(v[8], v[9]), pack2(v[10], v[11])};
                 }
+                if (last_pair) nlast = __builtin_amdgcn_readfirstlane(two ? 4 : 2);
             }
         }
+        for (; pk < NSP; ++pk) piece(nx, pk);   // waves without fragments in this tile (and inactive ones)
     }
 }
 

@@ -212,7 +212,7 @@ struct hrn_ctx {
     bool disable_s2 = getenv("HRN_DISABLE_S2") != nullptr;
     // the slab kernel is taken when a launch has at least this many tiles (one per CU); smaller calls use the generic kernel
     int s2_min_tiles = getenv("HRN_S2_MIN_TILES") ? atoi(getenv("HRN_S2_MIN_TILES")) : 256;
-    int s2_target_blocks = getenv("HRN_S2_BLOCKS") ? std::max(1, atoi(getenv("HRN_S2_BLOCKS"))) : 512;   // 96-cout form off: those convolutions take the (48, 3) form
+    int s2_target_blocks = getenv("HRN_S2_BLOCKS") ? std::max(1, atoi(getenv("HRN_S2_BLOCKS"))) : 256;   // 96-cout form off: those convolutions take the (48, 3) form
     bool disable_stem_mfma = getenv("HRN_DISABLE_STEM_MFMA") != nullptr;
     bool disable_head_mfma = getenv("HRN_DISABLE_HEAD_MFMA") != nullptr;
     bool direct_nr6 = getenv("HRN_DIRECT_NR6") ? atoi(getenv("HRN_DIRECT_NR6")) != 0 : true;
@@ -988,7 +988,7 @@ struct hrn_ctx {
             const S2Group::Prob &pr = g.probs[k];
             const Tensor &to = tensors[convs[pr.parts[0].first].out_t];
             const int frags = (pr.rows * to.wp + 15) / 16;
-            const int wm = 8 / (int)pr.parts.size() ? 8 / (int)pr.parts.size() : 1;
+            const int wm = std::max(1, 8 / (int)pr.parts.size());     // fewest waves sharing a part
             cost[k] = (double)((frags + wm - 1) / wm) * 14 * 3 + 60;   // MFMAs of the busiest wave + per-tile overhead
             total += cost[k] * nb * pr.tiles_per_image;
         }
@@ -1012,6 +1012,32 @@ struct hrn_ctx {
         return (int)ents.size();
     }
 
+    // Eight waves over P parts: 8 / P waves per part (the first 8 % P parts one more), the waves of a part deal its pixel
+    // fragments round-robin.  Wave w runs on SIMD w % 4: waves are placed so that the four SIMDs carry equal shares
+    // (3 parts: 3 + 3 + 2 waves -> per-SIMD load 10 : 10 : 8 : 8 twelfths instead of 12 : 12 : 6 : 6 with 2 + 2 + 2).
+    static void s2_wave_table(int nparts, unsigned char *part, unsigned char *f0, unsigned char *fs) {
+        struct W {
+            int p, i, m;
+        };
+        std::vector<W> ws;
+        for (int p = 0; p < nparts; ++p) {
+            const int m = std::max(1, 8 / nparts + (p < 8 % nparts ? 1 : 0));
+            for (int i = 0; i < m && (int)ws.size() < 8; ++i) ws.push_back({p, i, m});
+        }
+        std::stable_sort(ws.begin(), ws.end(), [](const W &a, const W &b) { return a.m < b.m; });  // heaviest (fewest sharers) first
+        double load[4] = {0, 0, 0, 0};
+        bool used[8] = {};
+        for (int w = 0; w < 8; ++w) part[w] = 0xff, f0[w] = 0, fs[w] = 1;
+        for (const W &x : ws) {
+            int best = -1;
+            for (int w = 0; w < 8; ++w)
+                if (!used[w] && (best < 0 || load[w & 3] < load[best & 3] - 1e-12)) best = w;
+            used[best] = true;
+            load[best & 3] += 1.0 / x.m;
+            part[best] = (unsigned char)x.p, f0[best] = (unsigned char)x.i, fs[best] = (unsigned char)x.m;
+        }
+    }
+
     bool setup_s2groups() {
         const size_t nprob = index_s2groups();
         if (!nprob) return true;
@@ -1026,7 +1052,7 @@ struct hrn_ctx {
                 q.ho = to.h, q.wo = to.w, q.wop = to.wp, q.out_hpwp = to.hpwp;
                 q.rows = pr.rows, q.tiles_per_image = pr.tiles_per_image;
                 q.nparts = (int)pr.parts.size();
-                q.wm = 8 / q.nparts < 1 ? 1 : 8 / q.nparts;
+                s2_wave_table(q.nparts, q.wave_part, q.wave_f0, q.wave_fs);
                 fast_div(to.wp, &q.magic_wop, &q.shift_wop);
                 for (int i = 0; i < q.nparts; ++i) {
                     const ConvOp &cv = convs[pr.parts[i].first];

@@ -80,7 +80,9 @@ struct S2Problem {
     int ho, wo, wop, out_hpwp;   // output geometry (shared by all parts)
     int rows;                    // output rows per tile
     int tiles_per_image;         // ceil(ho / rows)
-    int nparts, wm;              // cout groups; waves per group = 8 / nparts (wave -> (group, share of the fragments))
+    int nparts;                  // cout groups of 48
+    // wave w works on part wave_part[w] (0xff: idle) and on the pixel fragments wave_f0[w], + wave_fs[w], ... of every tile
+    unsigned char wave_part[8], wave_f0[8], wave_fs[8];
     unsigned magic_wop;          // x / wop == (x * magic) >> shift
     int shift_wop;
     S2Part part[kS2MaxParts];
