@@ -16,6 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libhrnet_mi355.so")
+if os.environ.get("HRN_LIB_TAG"):   # A/B runs of compile-time variants (tools/mkvariant.sh builds libhrnet_mi355_<tag>.so beforehand)
+    LIB_PATH = LIB_PATH.replace(".so", "_%s.so" % os.environ["HRN_LIB_TAG"])
 SOURCES = ["kernels.hip", "conv3x3_lds.hip", "conv_s2.hip", "bottleneck_chain.hip", "prepath.hip", "nms.hip", "postproc.cpp", "hrnet_mi355.cpp"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv3x3_n96.inc"), os.path.join(INCLUDE, "hrnet_mi355.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
@@ -31,6 +33,8 @@ def _hipcc() -> str:
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
+    if os.environ.get("HRN_LIB_TAG"):
+        return False                  # a tagged variant is used as built
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)

@@ -36,6 +36,9 @@ namespace {
 constexpr int CIN = 48, ROWB = CIN * 2, UPR = CIN / 8;   // bytes and 16-byte units per slot
 constexpr int NCH = 14;                                   // K = 9*48 = 432 -> 14 chunks of 32 (the last one half zero)
 constexpr int NT = 512;
+#ifndef S2_DEPTH
+#define S2_DEPTH 1
+#endif
 constexpr int NSP = (kS2SlabBytes / 16 + NT - 1) / NT;    // LDS-DMA pieces per thread for a full slab
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
@@ -191,21 +194,23 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                s16x8 xf[2][2];
+                // pixel fragments are requested S2_DEPTH chunks ahead (ring of S2_DEPTH + 1 register sets)
+                s16x8 xf[S2_DEPTH + 1][2];
 #define S2_READ(SET, C)                                                                                   \
     {                                                                                                     \
         asm volatile("ds_read_b128 %0, %1" : "=v"(xf[SET][0]) : "v"(xa[0] + (unsigned)xoff[C]));          \
         asm volatile("ds_read_b128 %0, %1" : "=v"(xf[SET][1]) : "v"(xa[1] + (unsigned)xoff[C]));          \
     }
-                S2_READ(0, 0)
+#pragma unroll
+                for (int c = 0; c < S2_DEPTH; ++c) S2_READ(c, c)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const int cur = c & 1;
-                    if (c + 1 < NCH) {
-                        S2_READ(cur ^ 1, c + 1)
-                        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");   // chunk c landed, c + 1 in flight
+                    const int cur = c % (S2_DEPTH + 1);
+                    if (c + S2_DEPTH < NCH) {
+                        S2_READ((c + S2_DEPTH) % (S2_DEPTH + 1), c + S2_DEPTH)
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(2 * S2_DEPTH) : "memory");   // chunk c landed, the next ones in flight
                     } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(2 * (NCH - 1 - c)) : "memory");
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
