@@ -150,8 +150,14 @@ int hrn_forward_flip_tta(hrn_handle h, const void *images_dev, int n, const int3
  * Same contract: boxes sorted by score descending, rows [x1,y1,x2,y2,score,...], IoU with the +1 pixel convention,
  * a box is dropped when its IoU with an earlier kept box is > thresh; keep_out receives the kept row indices in
  * order, *num_out their count.  Needs no handle.  Returns 0 or an error code (hrn_nms_last_error()). */
+/* SYNCHRONOUS like the reference's _nms (host boxes in, host indices out: two blocking copies on the default stream around
+ * the kernels) -- it is the one entry point of this ABI that is not stream-ordered.  At most 65536 boxes (the n x n/64
+ * suppression mask is the scratch that grows quadratically: 512 MiB there); the caller's current device is restored.
+ * Scratch is kept per device between calls (the reference allocates and frees per call); hrn_nms_release(device_id) frees
+ * it (device_id < 0: on every device). */
 int hrn_nms(int32_t *keep_out, int32_t *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
             float nms_overlap_thresh, int device_id);
+int hrn_nms_release(int device_id);
 const char *hrn_nms_last_error(void);
 
 /* ---- pose post-processing on the host (O(people^2 * joints) on a handful of skeletons: host code in the reference,

@@ -104,6 +104,7 @@ SYMBOLS = {
     "hrn_preprocess_frame": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
     "hrn_forward_flip_tta": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
     "hrn_nms": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]),
+    "hrn_nms_release": (ctypes.c_int, [ctypes.c_int]),
     "hrn_nms_last_error": (ctypes.c_char_p, []),
     "hrn_oks_nms": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, _P, ctypes.c_double]),
     "hrn_soft_oks_nms": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, _P, ctypes.c_double]),

@@ -71,6 +71,7 @@ struct MapSlot {
     int2 *dev = nullptr, *pin = nullptr;
     ConvArgs *args_dev = nullptr, *args_pin = nullptr;  // generic kernel only
     hipEvent_t landed = nullptr;
+    hipStream_t up_stream = nullptr;   // the stream the upload went out on: a hit from ANOTHER stream waits for `landed` first
     uint64_t stamp = 0;
 };
 
@@ -229,6 +230,8 @@ struct hrn_ctx {
     size_t pre_tmp_bytes = 0;
     ResizeTaps *rs_taps = nullptr;   // single-person pre-path: tap tables of the last (frame size, interpolation), device
     int rs_taps_cap = 0;
+    hipEvent_t rs_done = nullptr;    // recorded behind the last resize launch: a call on ANOTHER stream rewrites the table after it
+    hipStream_t rs_stream = nullptr;
     CropParams *pre_params = nullptr;
     int pre_params_cap = 0;
     // pinned host image of one call's crop parameters + boxes (the async uploads read it after the call returned);
@@ -1112,6 +1115,14 @@ struct hrn_ctx {
         return lru;
     }
 
+    // a cached map was uploaded on sl->up_stream; a launch on another stream has to see that upload (callers that
+    // alternate streams on one handle -- predict_stream, user code under torch.cuda.stream)
+    hipError_t slot_ready(MapSlot *sl, bool hit, hipStream_t s) {
+        if (hit && sl->up_stream != s) return hipStreamWaitEvent(s, sl->landed, 0);
+        if (!hit) sl->up_stream = s;
+        return hipSuccess;
+    }
+
     // descriptor numbering of the grouped launches (host only; plan-only handles need it for hrn_plan_block_map)
     size_t index_groups() {
         size_t nprob = 0;
@@ -1185,6 +1196,8 @@ struct hrn_ctx {
             if (pre_tmp) (void)hipFree(pre_tmp);
             if (rs_taps) (void)hipFree(rs_taps);
             rs_taps = nullptr, rs_taps_cap = 0;
+            if (rs_done) (void)hipEventDestroy(rs_done);
+            rs_done = nullptr;
             if (pre_params) (void)hipFree(pre_params);
             if (part_val) (void)hipFree(part_val);
             if (part_idx) (void)hipFree(part_idx);
@@ -1506,6 +1519,7 @@ struct hrn_ctx {
             Conv3Group &g = groups[op.idx];
             bool hit;
             MapSlot *sl = find_slot(g.slot, nb, &hit);
+            if ((e = slot_ready(sl, hit, s)) != hipSuccess) break;
             if (!hit) {  // block map depends on the micro-batch size: build it once per size (kMapSlots sizes kept)
                 sl->nblocks = group_blocks(g, nb, &g.map_host, rev);
                 memcpy(sl->pin, g.map_host.data(), (size_t)sl->nblocks * sizeof(int2));
@@ -1523,6 +1537,7 @@ struct hrn_ctx {
             DirectGroup &g = dgroups[op.idx];
             bool hit;
             MapSlot *sl = find_slot(g.slot, nb, &hit);
+            if ((e = slot_ready(sl, hit, s)) != hipSuccess) break;
             if (!hit) {  // descriptors (row counts) and block map depend on the micro-batch size
                 for (size_t k = 0; k < g.conv_idx.size(); ++k) sl->args_pin[k] = conv_args(convs[g.conv_idx[k]], nb, rev);
                 sl->mr = 4;  // shorter M tiles for small launches: fill the chip, shorten the serial K loop per block
@@ -1551,6 +1566,7 @@ struct hrn_ctx {
             }
             bool hit;
             MapSlot *sl = find_slot(g.slot, nb, &hit);
+            if ((e = slot_ready(sl, hit, s)) != hipSuccess) break;
             if (!hit) {
                 sl->nblocks = s2_blocks(g, nb, &g.map_host);
                 memcpy(sl->pin, g.map_host.data(), (size_t)sl->nblocks * sizeof(int2));
@@ -1971,8 +1987,14 @@ int hrn_resize_frames(hrn_handle h, const uint8_t *frames_dev, int n, int frame_
         if (!h->hip_ok(hipMalloc((void **)&h->rs_taps, (size_t)(W + H) * sizeof(ResizeTaps)), "hipMalloc(resize taps)")) return 6;
         h->rs_taps_cap = W + H;
     }
+    // the one tap table of the handle is rewritten by every call: a call on another stream than the previous one waits until
+    // that one's kernels have read it (same stream: ordered anyway)
+    if (h->rs_done && h->rs_stream != s && !h->hip_ok(hipStreamWaitEvent(s, h->rs_done, 0), "hipStreamWaitEvent")) return 6;
+    if (!h->rs_done && !h->hip_ok(hipEventCreateWithFlags(&h->rs_done, hipEventDisableTiming), "hipEventCreate")) return 6;
     if (!h->hip_ok(launch_resize_frames(frames_dev, n, frame_h, frame_w, interpolation, h->rs_taps, images_dev, H, W, s), "resize launch"))
         return 8;
+    h->rs_stream = s;
+    if (!h->hip_ok(hipEventRecord(h->rs_done, s), "hipEventRecord")) return 6;
     return 0;
 }
 

@@ -127,14 +127,24 @@ extern "C" int hrn_nms(int32_t *keep_out, int32_t *num_out, const float *boxes_h
     *num_out = 0;
     if (boxes_num == 0) return 0;
     const int col_blocks = (boxes_num + 63) / 64;
-    if ((size_t)col_blocks * 8 > 64 * 1024) {
-        g_nms_error = "more than 524288 boxes (the suppression words of the sweep no longer fit 64 KiB of LDS)";
+    // the n x ceil(n / 64) bit mask is the scratch that grows quadratically: 65536 boxes = 512 MiB, the cap (a detector
+    // emits thousands; the reference itself allocates the same mask per call)
+    if (boxes_num > 65536) {
+        g_nms_error = "more than 65536 boxes (the n x n / 64 suppression mask would exceed 512 MiB)";
         return 2;
     }
     if (device_id < 0 || device_id >= kMaxDevices) {
         g_nms_error = "bad device id";
         return 1;
     }
+    // the caller's current device is restored on every path out (the reference's _nms leaves it changed: gpu_nms.hpp)
+    struct DeviceGuard {
+        int prev = -1;
+        DeviceGuard() { (void)hipGetDevice(&prev); }
+        ~DeviceGuard() {
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    } guard;
     if (!ok(hipSetDevice(device_id), "hipSetDevice")) return 3;
     Scratch &sc = g_scratch[device_id];
     std::lock_guard<std::mutex> lock(sc.mu);
@@ -156,5 +166,25 @@ extern "C" int hrn_nms(int32_t *keep_out, int32_t *num_out, const float *boxes_h
         !ok(hipMemcpy(num_out, sc.keep + boxes_num, 4, hipMemcpyDeviceToHost), "hipMemcpy(num_out)") ||
         !ok(hipMemcpy(keep_out, sc.keep, (size_t)(*num_out) * 4, hipMemcpyDeviceToHost), "hipMemcpy(keep)"))
         return 4;
+    return 0;
+}
+
+// frees the per-device scratch (boxes, mask, kept indices) hrn_nms keeps between calls; device_id < 0: every device
+extern "C" int hrn_nms_release(int device_id) {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (int d = 0; d < kMaxDevices; ++d) {
+        if (device_id >= 0 && d != device_id) continue;
+        Scratch &sc = g_scratch[d];
+        std::lock_guard<std::mutex> lock(sc.mu);
+        if (!sc.boxes && !sc.mask && !sc.keep) continue;
+        if (hipSetDevice(d) != hipSuccess) continue;
+        if (sc.boxes) (void)hipFree(sc.boxes);
+        if (sc.mask) (void)hipFree(sc.mask);
+        if (sc.keep) (void)hipFree(sc.keep);
+        sc.boxes = nullptr, sc.mask = nullptr, sc.keep = nullptr;
+        sc.boxes_bytes = sc.mask_bytes = sc.keep_bytes = 0;
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
     return 0;
 }

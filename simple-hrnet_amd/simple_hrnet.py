@@ -33,13 +33,25 @@ _MEAN = (0.485, 0.456, 0.406)   # SimpleHRNet.py:171
 _STD = (0.229, 0.224, 0.225)
 
 
+def _launcher_local_rank() -> Optional[int]:
+    """the local rank a multi-process launcher gave this process, or None for a plain process.  ``torch.distributed.run`` sets
+    LOCAL_RANK; srun / mpirun set their own variables and no LOCAL_RANK -- under any of them a process drives ONE GPU (a
+    rank that built an engine on every visible GPU would oversubscribe the node)."""
+    for key in ("LOCAL_RANK", "SLURM_LOCALID", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID"):
+        if key in os.environ:
+            return int(os.environ[key])
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ:   # a launcher without a local-rank variable
+        return int(os.environ["RANK"]) % max(1, torch.cuda.device_count())
+    return None
+
+
 def resolve_device(device, local_rank: Optional[int] = None) -> torch.device:
     """The reference's device argument (``SimpleHRNet.py:123-139``) mapped onto one-process-per-GPU: ``'cuda:3'`` is that
     GPU; ``'cuda'`` (all GPUs through DataParallel there) and ``'cuda:1,2'`` (the listed ones) name the set this job runs
     on, of which THIS process takes the entry of its ``LOCAL_RANK`` (0 when not launched by ``torch.distributed.run``).
     Anything that is not CUDA raises, as the reference does for a wrong name -- there is no CPU path here."""
     if local_rank is None:
-        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        local_rank = _launcher_local_rank() or 0
     if device is None:
         return torch.device("cuda", local_rank)
     if isinstance(device, torch.device):
@@ -61,14 +73,17 @@ def resolve_device(device, local_rank: Optional[int] = None) -> torch.device:
 
 def resolve_devices(device) -> list:
     """GPU indices THIS process drives for the reference's ``device`` argument.  Launched by ``torch.distributed.run``
-    (``LOCAL_RANK`` set): exactly one, ``resolve_device``'s.  A plain process: ``'cuda'`` = every visible GPU,
+    or another multi-process launcher (``LOCAL_RANK`` / ``SLURM_LOCALID`` / ``OMPI_COMM_WORLD_LOCAL_RANK`` / ``RANK`` +
+    ``WORLD_SIZE``): exactly one, ``resolve_device``'s.  A plain process: ``'cuda'`` = every visible GPU,
     ``'cuda:1,2'`` = those (an index may repeat), ``'cuda:3'`` / ``torch.device('cuda', 3)`` = that one, ``None`` = GPU 0."""
-    if "LOCAL_RANK" in os.environ:
+    if _launcher_local_rank() is not None:
         return [resolve_device(device).index]
     if device is None:
         return [0]
     if isinstance(device, torch.device):
-        return list(range(torch.cuda.device_count())) if (device.type == "cuda" and device.index is None) else [resolve_device(device).index]
+        if device.type == "cuda" and device.index is None:
+            return list(range(max(1, torch.cuda.device_count())))   # (no visible GPU: index 0, and the engine says so when created)
+        return [resolve_device(device).index]
     name = str(device)
     if name == "cuda":
         return list(range(max(1, torch.cuda.device_count())))
