@@ -15,7 +15,9 @@
  *     available from hrn_last_error() (the reference raises Python exceptions:
  *     SimpleHRNet.py:107,114,139,210 -- the ctypes shim turns our codes back into them);
  *   - a handle is bound to one GPU; it is not thread-safe, distinct handles are;
- *   - all work is stream-ordered on `stream`; nothing allocates inside hrn_forward().
+ *   - all work is stream-ordered on `stream`; nothing allocates inside hrn_forward().  A handle has ONE workspace: calls
+ *     on different streams are serialised on the device by the handle itself (a call on another stream than the previous
+ *     one first waits for that one's last kernel) -- concurrency comes from several handles, not from several streams;
  */
 #ifndef HRNET_MI355_H
 #define HRNET_MI355_H

@@ -230,6 +230,20 @@ struct hrn_ctx {
     size_t pre_tmp_bytes = 0;
     ResizeTaps *rs_taps = nullptr;   // single-person pre-path: tap tables of the last (frame size, interpolation), device
     int rs_taps_cap = 0;
+    // One workspace per handle: passes on DIFFERENT streams must not overlap on the device.  Every entry point that runs a pass
+    // records `pass_done` behind it; a call on another stream than the previous one waits for that event first (same stream:
+    // ordered anyway, nothing is waited for).
+    hipEvent_t pass_done = nullptr;
+    hipStream_t pass_stream = nullptr;
+    bool pass_enter(hipStream_t s) {
+        if (pass_done && pass_stream != s) return hip_ok(hipStreamWaitEvent(s, pass_done, 0), "hipStreamWaitEvent");
+        return true;
+    }
+    bool pass_leave(hipStream_t s) {
+        if (!pass_done && !hip_ok(hipEventCreateWithFlags(&pass_done, hipEventDisableTiming), "hipEventCreate")) return false;
+        pass_stream = s;
+        return hip_ok(hipEventRecord(pass_done, s), "hipEventRecord");
+    }
     hipEvent_t rs_done = nullptr;    // recorded behind the last resize launch: a call on ANOTHER stream rewrites the table after it
     hipStream_t rs_stream = nullptr;
     CropParams *pre_params = nullptr;
@@ -1198,6 +1212,8 @@ struct hrn_ctx {
             rs_taps = nullptr, rs_taps_cap = 0;
             if (rs_done) (void)hipEventDestroy(rs_done);
             rs_done = nullptr;
+            if (pass_done) (void)hipEventDestroy(pass_done);
+            pass_done = nullptr;
             if (pre_params) (void)hipFree(pre_params);
             if (part_val) (void)hipFree(part_val);
             if (part_idx) (void)hipFree(part_idx);
@@ -1777,6 +1793,7 @@ int hrn_forward(hrn_handle h, const void *images_dev, int n, const void *boxes_d
     if (!h->check_forward_args(images_dev, n, boxes_dev, pts_dev, heatmaps_dev)) return 7;
     if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return 6;
     const int hm = (h->H / 4) * (h->W / 4);
+    if (n > 0 && !h->pass_enter((hipStream_t)stream)) return 6;
     for (int off = 0; off < n; off += h->max_batch) {
         const int nb = n - off < h->max_batch ? n - off : h->max_batch;
         const float *img = (const float *)images_dev + (size_t)off * 3 * h->H * h->W;
@@ -1785,6 +1802,7 @@ int hrn_forward(hrn_handle h, const void *images_dev, int n, const void *boxes_d
         float *hp = heatmaps_dev ? heatmaps_dev + (size_t)off * h->joints * hm : nullptr;
         if (!h->run_pass(img, nb, bx, box_dtype, p, hp, (hipStream_t)stream, nullptr)) return 8;
     }
+    if (n > 0 && !h->pass_leave((hipStream_t)stream)) return 6;
     return 0;
 }
 
@@ -1818,6 +1836,7 @@ int hrn_forward_flip_tta(hrn_handle h, const void *images_dev, int n, const int3
         !h->hip_ok(hipMalloc((void **)&h->tta_hm, (size_t)h->max_batch * h->joints * hm * sizeof(float)), "hipMalloc(flip-TTA)"))
         return 6;
     hipStream_t s = (hipStream_t)stream;
+    if (!h->pass_enter(s)) return 6;
     for (int off = 0; off < n; off += h->max_batch) {
         const int nb = n - off < h->max_batch ? n - off : h->max_batch;
         const float *img = (const float *)images_dev + (size_t)off * 3 * h->H * h->W;
@@ -1829,7 +1848,7 @@ int hrn_forward_flip_tta(hrn_handle h, const void *images_dev, int n, const int3
         a.n = nb, a.joints = h->joints, a.h = hh, a.w = ww, a.post_processing = post_processing;
         if (!h->hip_ok(launch_tta_decode(a, s), "flip-TTA decode launch")) return 8;
     }
-    return 0;
+    return h->pass_leave(s) ? 0 : 6;
 }
 
 // SimpleHRNet.py:236-278.  The box arithmetic is Python's, restated in double: round() is round-half-even on a
@@ -2033,7 +2052,9 @@ int hrn_forward_tap(hrn_handle h, const void *images_dev, int n, const char *tap
     }
     if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return 6;
     const TapReq req{tp->op, tp->tensor, crop0, ncrops, crop_step, dst_dev};
-    return h->run_pass((const float *)images_dev, n, nullptr, 0, nullptr, heatmaps_dev, (hipStream_t)stream, nullptr, 0, &req) ? 0 : 8;
+    if (!h->pass_enter((hipStream_t)stream)) return 6;
+    if (!h->run_pass((const float *)images_dev, n, nullptr, 0, nullptr, heatmaps_dev, (hipStream_t)stream, nullptr, 0, &req)) return 8;
+    return h->pass_leave((hipStream_t)stream) ? 0 : 6;
 }
 
 int hrn_conv_count(hrn_handle h) { return h ? (int)h->convs.size() : 0; }
@@ -2137,7 +2158,8 @@ int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms
     tm.ev.resize(h->ops.size() + 1);
     for (auto &e : tm.ev)
         if (!h->hip_ok(hipEventCreate(&e), "hipEventCreate")) return 6;
-    bool ok = h->run_pass((const float *)images_dev, n, nullptr, 0, nullptr, nullptr, (hipStream_t)stream, &tm);
+    bool ok = h->pass_enter((hipStream_t)stream) &&
+              h->run_pass((const float *)images_dev, n, nullptr, 0, nullptr, nullptr, (hipStream_t)stream, &tm) && h->pass_leave((hipStream_t)stream);
     ok = ok && h->hip_ok(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
     if (ok) {
         if (other_ms) other_ms[0] = other_ms[1] = other_ms[2] = other_ms[3] = 0.f;
