@@ -899,6 +899,7 @@ int conv3x3_lds_bbf_ok(int wp) { return (512 + 4 * (wp + 1)) * 6 <= BBF_XY / 16;
 
 // pixels per M tile for a (KS, wp) pair: 512, or 384 when two 512-row slabs (+ halo) would not fit in LDS; 0 = unsupported
 int conv3x3_lds_bm(int ks, int nrb, int wp) {
+    if (ks == 16) return conv3x3_f32_bm(wp);   // fp32 kernel
     if (ks == 32 && nrb == 6) return 512 + 2 * wp + 2 <= N96_MAXROWS ? 512 : 384 + 2 * wp + 2 <= N96_MAXROWS ? 384 : 0;
     const int maxrows = ks == 48 ? C3Cfg<48, 3>::MAXROWS : C3Cfg<32, 4>::MAXROWS;
     if (nrb != 4 && 512 + 2 * wp + 2 <= maxrows) return 512;
@@ -910,6 +911,7 @@ hipError_t launch_conv3x3_lds(const Conv3Problem *probs_dev, const void *blockma
                               int nrb, hipStream_t s) {
     if (nblocks <= 0) return hipSuccess;
     const int2 *bm = (const int2 *)blockmap_dev;
+    if (ks == 16) return launch_conv3x3_f32(probs_dev, blockmap_dev, nblocks, nb, nrb, s);
     if ((ks == 48 && nrb == 3) || (ks == 32 && nrb == 6)) return launch_c3<48, 3>(probs_dev, bm, nblocks, nb, s);
     if (ks == 32 && nrb == 4) return launch_c3<32, 4>(probs_dev, bm, nblocks, nb, s);
     if (ks == 32 && nrb == 3) return launch_c3<32, 3>(probs_dev, bm, nblocks, nb, s);

@@ -209,6 +209,7 @@ struct hrn_ctx {
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
     bool disable_n96 = getenv("HRN_DISABLE_N96") != nullptr;
+    bool disable_f32lds = getenv("HRN_DISABLE_F32LDS") != nullptr;   // fp32 3x3 stride-1 convs back on the generic kernel
     // stride-2 slab kernel (conv_s2.hip) off: those convolutions stay on the generic kernel (bit-identical results)
     bool disable_s2 = getenv("HRN_DISABLE_S2") != nullptr;
     // the slab kernel is taken when a launch has at least this many tiles (one per CU); smaller calls use the generic kernel
@@ -340,6 +341,14 @@ struct hrn_ctx {
             op.algo = 1, op.ks = lds_ks, op.nr = lds_nrb;
             op.slices = op.cin / lds_ks, op.ntiles = cout / (16 * lds_nrb), op.nch = (9 * lds_ks + 31) / 32;
             op.kpad = op.nch * 32 * op.slices;
+        }
+        // fp32 (the parity mode): the LDS-staged fp32 kernel (conv3x3_f32.hip) -- 16-channel slices, one K chunk of 16 per tap,
+        // 48- or 32-cout tiles; everything whose channel counts allow it, at every batch size (its K order is its own)
+        if (dtype == HRN_F32 && k == 3 && stride == 1 && !up && !disable_lds && !disable_f32lds && op.cin % 16 == 0 &&
+            (cout % 48 == 0 || cout % 32 == 0) && conv3x3_lds_bm(16, cout % 48 == 0 ? 3 : 2, ow + 1) > 0) {
+            op.algo = 1, op.ks = 16, op.nr = cout % 48 == 0 ? 3 : 2;
+            op.slices = op.cin / 16, op.ntiles = cout / (16 * op.nr), op.nch = 9;
+            op.kpad = 9 * 16 * op.slices;
         }
         if (dtype == HRN_BF16 && k == 3 && stride == 2 && op.cin == 48 && cout % 48 == 0 && !up && !disable_s2 && op.algo == 0 &&
             s2_rows(ow + 1, oh) >= 1)
@@ -1437,6 +1446,21 @@ struct hrn_ctx {
     // [chunk c][frag j][lane][8 bf16]; within a slice k = tap*KS + ci_local, zero beyond 9*KS.
     void pack_conv_lds(const ConvOp &cv, const float *wf, int K, char *dst) const {
         const int KS = cv.ks, NRB = cv.nr;
+        if (KS == 16) {  // fp32 form (conv3x3_f32.hip): [cout tile][slice][9 taps][frag][lane][4 fp32], k = 4 g + e of the slice's 16
+            for (int t = 0; t < cv.ntiles; ++t)
+                for (int s = 0; s < cv.slices; ++s) {
+                    float *blk = (float *)(dst + ((size_t)t * cv.slices + s) * cv.nch * NRB * 1024);
+                    for (int c = 0; c < 9; ++c)
+                        for (int j = 0; j < NRB; ++j)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int li = lane & 15, g = lane >> 4;
+                                const int co = t * 16 * NRB + (li >> 2) * 4 * NRB + j * 4 + (li & 3);
+                                for (int e = 0; e < 4; ++e)
+                                    blk[((size_t)(c * NRB + j) * 64 + lane) * 4 + e] = wf[(size_t)co * K + c * cv.cin + s * 16 + 4 * g + e];
+                            }
+                }
+            return;
+        }
         for (int t = 0; t < cv.ntiles; ++t)
             for (int s = 0; s < cv.slices; ++s) {
                 uint16_t *blk = (uint16_t *)(dst + ((size_t)t * cv.slices + s) * cv.nch * NRB * 1024);

@@ -60,7 +60,9 @@ struct Conv3Problem {
 };
 int conv3x3_n96_ch64();           // output-channel permutation of the 96-cout form's weight image (conv3x3_n96.inc)
 int conv3x3_lds_bbf_ok(int wp);  // the fused BasicBlock kernel fits this row pitch
-int conv3x3_lds_bm(int ks, int nrb, int wp);  // (32, 6) = the 96-cout form
+int conv3x3_lds_bm(int ks, int nrb, int wp);  // (32, 6) = the 96-cout form; ks = 16: the fp32 kernel (conv3x3_f32.hip)
+int conv3x3_f32_bm(int wp);
+hipError_t launch_conv3x3_f32(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb, int nrb, hipStream_t s);
 
 // Stride-2 slab kernel (conv_s2.hip): every 3x3 / stride-2 convolution with 48 input channels that reads ONE tensor at one
 // fuse level is a "part" (48 output channels each) of one problem; a block stages the input slab of `rows` output rows once

@@ -66,8 +66,21 @@ def _unpack_lds(net, info):
     """inverse of the slice-major image of the LDS-staged 3x3 kernel:
     [cout tile][slice][chunk][frag][lane][8 bf16], k_local = tap*ks + ci_local per slice"""
     raw = net.read_blob(info.w_offset, info.w_bytes)
-    vals = (raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32)
     ks, nrb = info.ks, info.nr
+    if ks == 16:   # the fp32 form (conv3x3_f32.hip): [cout tile][slice][9 taps][frag][lane][4 fp32], k = 4 g + e
+        slices, ntiles = info.cin // 16, info.cout // (16 * nrb)
+        vals = raw.view(np.float32).reshape(ntiles, slices, 9, nrb, 64, 4)
+        out = np.zeros((info.cout, 9 * info.cin), np.float32)
+        for lane in range(64):
+            li, g = lane & 15, lane >> 4
+            for t in range(ntiles):
+                for j in range(nrb):
+                    co = t * 16 * nrb + (li >> 2) * 4 * nrb + j * 4 + (li & 3)
+                    for s in range(slices):
+                        for c in range(9):
+                            out[co, c * info.cin + s * 16 + 4 * g:c * info.cin + s * 16 + 4 * g + 4] = vals[t, s, c, j, lane]
+        return out
+    vals = (raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32)
     slices, ntiles, nch = info.cin // ks, info.cout // (16 * nrb), (9 * ks + 31) // 32
     vals = vals.reshape(ntiles, slices, nch, nrb, 64, 8)
     out = np.zeros((info.cout, 9 * info.cin), np.float32)
