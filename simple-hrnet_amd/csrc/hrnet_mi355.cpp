@@ -210,6 +210,7 @@ struct hrn_ctx {
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
     bool disable_n96 = getenv("HRN_DISABLE_N96") != nullptr;
     bool disable_f32lds = getenv("HRN_DISABLE_F32LDS") != nullptr;   // fp32 3x3 stride-1 convs back on the generic kernel
+    int f32_small_slices = getenv("HRN_F32_SMALL_SLICES") ? atoi(getenv("HRN_F32_SMALL_SLICES")) : 0;   // fp32: 128-pixel tiles from this many slices on (0: never; 4 and 8 measured: no gain)
     // stride-2 slab kernel (conv_s2.hip) off: those convolutions stay on the generic kernel (bit-identical results)
     bool disable_s2 = getenv("HRN_DISABLE_S2") != nullptr;
     // the slab kernel is taken when a launch has at least this many tiles (one per CU); smaller calls use the generic kernel
@@ -833,8 +834,13 @@ struct hrn_ctx {
         const bool small = small_tiles && one_per_block < small_below;
         // a fused BasicBlock walks 512-pixel tiles through both convolutions (no small-tile mode): about three
         // ordinary 384-pixel tiles' worth of work each
+        // fp32 form: a stage (one 16-channel slice of a 512-pixel tile) keeps a CU busy for ~8 us, so a one-tile block of the
+        // 256-channel branch would run 16 of them back to back while the launch as a whole is ~20 stages of work per CU:
+        // deep convolutions take 128-pixel tiles (the kernel picks the tile size per block) so that no block exceeds ~16
+        // quarter-stages and the launch can balance
+        auto small_conv = [&](const ConvOp &cv) { return small || (cv.ks == 16 && f32_small_slices > 0 && cv.slices >= f32_small_slices); };
         auto tile_px = [&](const ConvOp &cv, const Tensor &to) {
-            return fused_now(cv, nb) ? 512 : small ? 128 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
+            return fused_now(cv, nb) ? 512 : small_conv(cv) ? 128 : conv3x3_lds_bm(cv.ks, cv.nr, to.wp);
         };
         auto tiles_per_block = [&](const ConvOp &cv, int div) {
             return std::max(1, conv3_tiles_per_block(cv) / (fused_now(cv, nb) ? bbf_tpb_div : 1) / div);
@@ -890,15 +896,16 @@ struct hrn_ctx {
                             if (tiles > tpb) tiles = tpb;
                             double key = (i + 0.5) / total;  // proportional interleave of the problems
                             if (block_order == 1)            // longest-processing-time first (estimated block cost)
-                                key = -(double)tiles * (fused    ? 28000.0
-                                                        : cv.n96 ? cv.slices * 3.0 * (bm == 512 ? 3900.0 : 3000.0) + (bm == 512 ? 7000.0 : 5000.0)
+                                key = -(double)tiles * (fused         ? 28000.0
+                                                        : cv.ks == 16 ? cv.slices * (double)bm * 36.0 + 2000.0   // fp32: 9 x 4 MR NRB MFMAs of 32 cycles per slice
+                                                        : cv.n96      ? cv.slices * 3.0 * (bm == 512 ? 3900.0 : 3000.0) + (bm == 512 ? 7000.0 : 5000.0)
                                                                  : cv.slices * 2.0 * (bm == 512 ? 4300.0 : 3500.0) + (bm == 512 ? 5000.0 : 3000.0)) +
                                       1e-3 * key;
                             int mt0 = first + mg * tpb;
                             // every other launch walks the tensors backwards: a launch starts on what its producer
                             // wrote last, i.e. on the part most likely still in the Infinity Cache
                             if (reverse) mt0 = mtiles - mt0 - tiles;
-                            ents.push_back({key, int2{prob | (nt << 8) | (tiles << 16), mt0 | (fused ? 1 << 29 : small ? 1 << 30 : 0)}, bm});
+                            ents.push_back({key, int2{prob | (nt << 8) | (tiles << 16), mt0 | (fused ? 1 << 29 : small_conv(cv) ? 1 << 30 : 0)}, bm});
                         }
             }
         }
