@@ -147,7 +147,9 @@ hipError_t launch_prepath(const unsigned char *frame_dev, int frame_w, const Cro
 // (SimpleHRNet.py:213-222, 355-366) for 8-bit 3-channel frames.  OpenCV is a third-party dependency of the reference that is
 // not in this image: the arithmetic below follows the published generic path of modules/imgproc/src/resize.cpp (fixed-point
 // coefficients of 11 bits, int32 passes; see oracle/cv2_resize_oracle.py, which this kernel matches bit for bit) -- parity
-// with cv2 itself is UNPINNED.
+// with cv2 itself is UNPINNED.  It is OpenCV's SCALAR path: the SIMD builds of the stock wheels run the cubic vertical pass in
+// float32 (VResizeCubicVec_32s8u) and can differ from it by one grey level on some pixels;
+// tests/golden/make_cv2_golden.py makes the pin wherever opencv-python is installed.
 // Tap tables are formed on the device (no host staging): one thread per output column / row.
 __global__ __launch_bounds__(256) void resize_taps_kernel(int src_w, int src_h, int W, int H, double scale_x, double scale_y,
                                                           int interp, ResizeTaps *taps) {
