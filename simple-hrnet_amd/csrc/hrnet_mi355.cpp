@@ -124,6 +124,7 @@ struct FuseOp {
     int nterms;
     int out_t;
     std::string name;  // "<stage>.fuse.<i>": the i-th output of the module's fuse (debug tap)
+    int group = 1;     // this many consecutive fuses, starting here, go out as ONE launch (0: a member launched by its leader)
 };
 
 // Debug tap (hrn_forward_tap): a tensor some launch of the pass writes to HBM, by name
@@ -209,6 +210,7 @@ struct hrn_ctx {
     int dgroup_nr_mode = getenv("HRN_DGROUP_NR") ? atoi(getenv("HRN_DGROUP_NR")) : 1;
     bool disable_lds32 = getenv("HRN_DISABLE_LDS32") != nullptr;
     bool disable_n96 = getenv("HRN_DISABLE_N96") != nullptr;
+    bool disable_fgroup = getenv("HRN_DISABLE_FGROUP") != nullptr;   // one launch per fuse output instead of one per StageModule
     bool disable_f32lds = getenv("HRN_DISABLE_F32LDS") != nullptr;   // fp32 3x3 stride-1 convs back on the generic kernel
     int f32_small_slices = getenv("HRN_F32_SMALL_SLICES") ? atoi(getenv("HRN_F32_SMALL_SLICES")) : 0;   // fp32: 128-pixel tiles from this many slices on (0: never; 4 and 8 measured: no gain)
     // stride-2 slab kernel (conv_s2.hip) off: those convolutions stay on the generic kernel (bit-identical results)
@@ -464,7 +466,6 @@ struct hrn_ctx {
         (void)t0;
         f.out_t = new_tensor(tr.c, tr.h, tr.w);
         fuses.push_back(f);
-        ops.push_back({OP_FUSE, (int)fuses.size() - 1});
         return f.out_t;
     }
 
@@ -550,6 +551,13 @@ struct hrn_ctx {
             }
             snprintf(buf, sizeof buf, "%s.fuse.%d", name.c_str(), i);
             outs.push_back(add_fuse(terms, shifts, buf));
+        }
+        {   // the module's outputs are independent: one launch for all of them (HRN_DISABLE_FGROUP: one each)
+            const int first = (int)fuses.size() - nout;
+            for (int i = 0; i < nout; ++i) {
+                fuses[first + i].group = disable_fgroup ? 1 : (i == 0 ? nout : 0);
+                if (fuses[first + i].group) ops.push_back({OP_FUSE, first + i});
+            }
         }
         for (int i = 0; i < nout; ++i)
             for (int j = 0; j < nb; ++j)
@@ -729,7 +737,9 @@ struct hrn_ctx {
                     add(convs[chains[op.idx].conv3].conv, convs[chains[op.idx].conv3].out_t, (int)oi, chains[op.idx].conv3);
                     add(convs[chains[op.idx].conv1].conv, convs[chains[op.idx].conv1].out_t, (int)oi, chains[op.idx].conv1);
                     break;
-                case OP_FUSE: add(fuses[op.idx].name, fuses[op.idx].out_t, (int)oi, -1); break;
+                case OP_FUSE:
+                    for (int k = 0; k < fuses[op.idx].group; ++k) add(fuses[op.idx + k].name, fuses[op.idx + k].out_t, (int)oi, -1);
+                    break;
                 default: break;
             }
         }
@@ -1645,19 +1655,23 @@ struct hrn_ctx {
             break;
         }
         case OP_FUSE: {
-            const FuseOp &f = fuses[op.idx];
-            const Tensor &to = tensors[f.out_t];
-            FuseArgs a;
-            a.nterms = f.nterms;
-            for (int i = 0; i < f.nterms; ++i) {
-                const Tensor &tt = tensors[f.term_t[i]];
-                a.t[i].ptr = row0(f.term_t[i]), a.t[i].shift = f.shift[i];
-                a.t[i].wp = tt.wp, a.t[i].hpwp = tt.hpwp;
+            FuseGroupArgs ga;
+            ga.nf = fuses[op.idx].group;
+            for (int k = 0; k < ga.nf; ++k) {
+                const FuseOp &f = fuses[op.idx + k];
+                const Tensor &to = tensors[f.out_t];
+                FuseArgs &a = ga.f[k];
+                a.nterms = f.nterms;
+                for (int i = 0; i < f.nterms; ++i) {
+                    const Tensor &tt = tensors[f.term_t[i]];
+                    a.t[i].ptr = row0(f.term_t[i]), a.t[i].shift = f.shift[i];
+                    a.t[i].wp = tt.wp, a.t[i].hpwp = tt.hpwp;
+                }
+                for (int i = f.nterms; i < 4; ++i) a.t[i] = FuseTerm{nullptr, 0, 0, 0};
+                a.out = row0(f.out_t), a.c = to.c, a.h = to.h, a.w = to.w, a.wp = to.wp, a.hpwp = to.hpwp;
+                a.m = nb * to.hpwp, a.rev = rev;
             }
-            for (int i = f.nterms; i < 4; ++i) a.t[i] = FuseTerm{nullptr, 0, 0, 0};
-            a.out = row0(f.out_t), a.c = to.c, a.h = to.h, a.w = to.w, a.wp = to.wp, a.hpwp = to.hpwp;
-            a.m = nb * to.hpwp, a.rev = rev;
-            e = launch_fuse(dtype, a, s);
+            e = ga.nf == 1 ? launch_fuse(dtype, ga.f[0], s) : launch_fuse_group(dtype, ga, s);
             break;
         }
         case OP_HEAD: {

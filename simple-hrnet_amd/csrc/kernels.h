@@ -171,6 +171,13 @@ struct FuseArgs {          // out = relu(sum_j term_j) in order j = 0..nterms-1
     int rev;               // walk the rows backwards
 };
 
+struct FuseGroupArgs {     // up to four independent fuse outputs in one launch; block b belongs to f[k] with block_end[k-1] <= b < block_end[k]
+    FuseArgs f[4];
+    int nf;
+    int block_end[4];
+};
+hipError_t launch_fuse_group(int dtype, FuseGroupArgs &g, hipStream_t s);
+
 struct HeadArgs {          // final 1x1 conv (+bias) and per-(crop, joint) partial arg-max
     const void *in;        // fused branch 0, flat padded, c channels
     const float *wgt;      // [joints][c] fp32

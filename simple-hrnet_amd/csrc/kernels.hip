@@ -672,11 +672,11 @@ hipError_t launch_stem(int dtype, const StemArgs &a, hipStream_t s) {
 // A term with shift s is a lower-resolution tensor read at (r>>s, c>>s) (nn.Upsample nearest, integer
 // scale).  Pad pixels map to pad pixels, so zeros propagate without a mask.
 template <int DT>
-__global__ __launch_bounds__(256) void fuse_kernel(const FuseArgs p) {
+__device__ __forceinline__ void fuse_body(const FuseArgs &p, const long block, const long nblocks) {
     using T = Tr<DT>;
     using vec = typename T::vec;
     const int cvn = p.c / T::VEC;
-    const long bid = p.rev ? (long)gridDim.x - 1 - blockIdx.x : (long)blockIdx.x;
+    const long bid = p.rev ? nblocks - 1 - block : block;
     const long idx = bid * 256 + threadIdx.x;
     const long total = (long)p.m * cvn;
     if (idx >= total) return;
@@ -702,6 +702,31 @@ __global__ __launch_bounds__(256) void fuse_kernel(const FuseArgs p) {
     *(vec *)((typename T::elem *)p.out + (long)q * p.c + cv * T::VEC) = o;
 }
 
+template <int DT>
+__global__ __launch_bounds__(256) void fuse_kernel(const FuseArgs p) {
+    fuse_body<DT>(p, blockIdx.x, gridDim.x);
+}
+
+// all outputs of one StageModule's fuse (hrnet.py:60-69) in ONE launch: they are independent, and as separate launches each
+// of the three or four HBM-bound kernels pays its own ramp and drain (23 launches per pass -> 8)
+template <int DT>
+__global__ __launch_bounds__(256) void fuse_group_kernel(const FuseGroupArgs g) {
+    int k = 0;
+    long first = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (k == i && i + 1 < g.nf && (long)blockIdx.x >= g.block_end[i]) first = g.block_end[i], k = i + 1;
+    // (a by-value kernel argument indexed with a runtime k would live in scratch: pick with wave-uniform branches)
+    if (k == 0)
+        fuse_body<DT>(g.f[0], (long)blockIdx.x - first, (long)g.block_end[0] - first);
+    else if (k == 1)
+        fuse_body<DT>(g.f[1], (long)blockIdx.x - first, (long)g.block_end[1] - first);
+    else if (k == 2)
+        fuse_body<DT>(g.f[2], (long)blockIdx.x - first, (long)g.block_end[2] - first);
+    else
+        fuse_body<DT>(g.f[3], (long)blockIdx.x - first, (long)g.block_end[3] - first);
+}
+
 hipError_t launch_fuse(int dtype, const FuseArgs &a, hipStream_t s) {
     const long total = (long)a.m * (a.c / (dtype == DT_BF16 ? 8 : 4));
     if (total <= 0) return hipSuccess;
@@ -710,6 +735,21 @@ hipError_t launch_fuse(int dtype, const FuseArgs &a, hipStream_t s) {
         hipLaunchKernelGGL(fuse_kernel<DT_BF16>, grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(fuse_kernel<DT_F32>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fuse_group(int dtype, FuseGroupArgs &g, hipStream_t s) {
+    long end = 0;
+    for (int i = 0; i < g.nf; ++i) {
+        const long total = (long)g.f[i].m * (g.f[i].c / (dtype == DT_BF16 ? 8 : 4));
+        end += (total + 255) / 256;
+        g.block_end[i] = (int)end;
+    }
+    if (end <= 0) return hipSuccess;
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(fuse_group_kernel<DT_BF16>, dim3((unsigned)end), dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL(fuse_group_kernel<DT_F32>, dim3((unsigned)end), dim3(256), 0, s, g);
     return hipGetLastError();
 }
 

@@ -48,7 +48,7 @@ def _T():
 
 ENV_KEYS = ("HRN_DISABLE_N96", "HRN_BBF", "HRN_BBF_MIN_TILES", "HRN_DISABLE_LDS", "HRN_DISABLE_LDS32", "HRN_DISABLE_CHAIN",
             "HRN_DISABLE_CHAIN_DS", "HRN_DISABLE_S2", "HRN_DISABLE_STEM_MFMA", "HRN_DISABLE_HEAD_MFMA", "HRN_DISABLE_GROUP",
-            "HRN_DISABLE_DGROUP", "HRN_SMALL_TILES")
+            "HRN_DISABLE_DGROUP", "HRN_SMALL_TILES", "HRN_DISABLE_FGROUP")
 
 
 def _clear(monkeypatch):
