@@ -33,33 +33,30 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 namespace {
 
-constexpr int CIN = 48, ROWB = CIN * 2, UPR = CIN / 8;   // bytes and 16-byte units per slot
-constexpr int NCH = 14;                                   // K = 9*48 = 432 -> 14 chunks of 32 (the last one half zero)
 constexpr int NT = 512;
 #ifndef S2_DEPTH
 #define S2_DEPTH 1
 #endif
-constexpr int NSP = (kS2SlabBytes / 16 + NT - 1) / NT;    // LDS-DMA pieces per thread for a full slab
-
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
 
 __device__ __forceinline__ void glds16(const GLOBAL_AS void *gsrc, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-}  // namespace
-
-__global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__restrict__ probs, const int2 *__restrict__ map) {
-    extern __shared__ __attribute__((aligned(1024))) char smem_s2[];
-    const int2 e = map[blockIdx.x];
-    const int prob = __builtin_amdgcn_readfirstlane(e.x & 0xff), ntile = __builtin_amdgcn_readfirstlane(e.x >> 8);
-    const int tile0 = __builtin_amdgcn_readfirstlane(e.y);
-    const GLOBAL_AS S2Problem *pp = (const GLOBAL_AS S2Problem *)(probs + prob);
+// One configuration of the kernel: CIN input channels (a slot = CIN * 2 bytes of one input pixel, kept in LDS as CIN / 48
+// sub-slots of 96 bytes in separate regions so that the lane pitch of a fragment read stays 96 bytes), NF output-channel
+// fragments (16 couts each) per wave = per "part", MW pixel fragments processed together.
+//   <48, 3, 2>: 14 K chunks x 3 fragments = 168 weight VGPRs, 24 accumulators            (round 3, first form)
+//   <96, 2, 1>: 27 K chunks x 2 fragments = 216 weight VGPRs, 8 accumulators -- one pixel fragment at a time is what lets
+//               the whole 32 x 864 weight matrix of a part stay in registers
+template <int CIN, int NF, int MW>
+__device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int ntile, const int tile0, char *smem_s2) {
+    constexpr int HALVES = CIN / 48, ROWB = 96, UPR = 6;            // 96-byte sub-slots of 6 sixteen-byte units
+    constexpr int NCH = (9 * CIN + 31) / 32;                         // K chunks of 32 (cin = 48: the last one half zero)
+    constexpr int HALF_BYTES = kS2SlabBytes / HALVES;                // LDS region of one channel half within a slab buffer
+    constexpr int NSPH = (HALF_BYTES / 16 + NT - 1) / NT;            // LDS-DMA pieces per thread and half
+    constexpr int NSP = NSPH * HALVES;
+    constexpr int CPP = 16 * NF;                                     // couts per part
+    static_assert(HALF_BYTES % 1024 == 0, "a half starts on a whole LDS-DMA piece");
     // the descriptor's fields as scalars, once (a field read through a pointer is re-loaded after every "memory" clobber)
     const int in_wp = pp->in_wp, in_hpwp = pp->in_hpwp, Ho = pp->ho, Wo = pp->wo, Wop = pp->wop, out_hpwp = pp->out_hpwp;
     const int R = pp->rows, tpi = pp->tiles_per_image, nparts = pp->nparts;
@@ -77,14 +74,15 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
     const int part = active ? wpart : 0;
 
     char *const sbuf = smem_s2;
-    float *const bias_lds = (float *)(smem_s2 + 2 * kS2SlabBytes);   // [8][48]
+    float *const bias_lds = (float *)(smem_s2 + 2 * kS2SlabBytes);   // [8 parts][CPP]
 
-    // ---- LDS-DMA of a slab, one 1-KiB piece (64 lanes x 16 bytes) per call; piece k of this wave = units k*512 + wave*64 ...
+    // ---- LDS-DMA of a slab, one 1-KiB piece (64 lanes x 16 bytes) per call.  Piece k of a wave: half k / NSPH, units
+    //      (k % NSPH) * 512 + wave * 64 ... of that half's region; unit u = sub-slot u / 6, 16-byte piece u % 6
     const int slots_per_vrow = 2 * Wop;
     struct Slab {
         const GLOBAL_AS char *src;
         char *dst;
-        int units;
+        int units;   // per half
     };
     auto plan_slab = [&](int t, int b) {
         const int n = t / tpi, rg = t - n * tpi;
@@ -94,20 +92,21 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
         sl.units = (2 * rt + 1) * slots_per_vrow * UPR;
         // first pixel of the slab: row 2*h0 - 1, column -1 of image n (guard rows / the previous image's pad row when h0 == 0)
         const long px0 = (long)n * in_hpwp + (long)(2 * h0 - 1) * in_wp - 1;
-        sl.src = in + px0 * ROWB;
+        sl.src = in + px0 * (CIN * 2);
         sl.dst = sbuf + b * kS2SlabBytes;
         return sl;
     };
     auto piece = [&](const Slab &sl, int k) {
-        if (k * NT + wave * 64 < sl.units) {   // wave-uniform
-            int u = k * NT + tid;
-            if (u >= sl.units) u = sl.units - 1;  // tail lanes re-read a valid unit (their LDS slots lie inside the buffer, unused)
+        const int half = HALVES == 1 ? 0 : k / NSPH, kk = HALVES == 1 ? k : k - half * NSPH;
+        if (kk * NT + wave * 64 < sl.units) {   // wave-uniform
+            int u = kk * NT + tid;
+            if (u >= sl.units) u = sl.units - 1;  // tail lanes re-read a valid unit (their LDS slots lie inside the region, unused)
             const int slot = (int)(((unsigned)u * 43691u) >> 18);  // u / 6 for u < 2^15
             const int pc = u - slot * UPR;
             const int vrow = slot / slots_per_vrow, rem = slot - vrow * slots_per_vrow;
             const int plane = rem >= Wop ? 1 : 0, j = rem - plane * Wop;
-            const int rel = (vrow * in_wp + 2 * j + plane) * ROWB + pc * 16;
-            glds16(sl.src + rel, sl.dst + (k * NT + wave * 64) * 16);
+            const int rel = (vrow * in_wp + 2 * j + plane) * (CIN * 2) + half * ROWB + pc * 16;
+            glds16(sl.src + rel, sl.dst + half * HALF_BYTES + (kk * NT + wave * 64) * 16);
         }
     };
 
@@ -117,33 +116,52 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
         for (int k = 0; k < NSP; ++k) piece(s0, k);
     }
 
-    // ---- this wave's weights: 14 chunks x 3 fragments, resident in registers; its bias -> LDS
-    s16x8 wf[NCH][3];
+    // ---- this wave's weights: NCH chunks x NF fragments, resident in registers; the biases -> LDS
+    s16x8 wf[NCH][NF];
     {
         const GLOBAL_AS char *wsrc = (const GLOBAL_AS char *)pp->part[part].w + lane * 16;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) wf[c][j] = *(const GLOBAL_AS s16x8 *)(wsrc + (c * 3 + j) * 1024);
-        if (tid < nparts * 48) {
-            const int pt = tid / 48, ch = tid - pt * 48;
-            bias_lds[pt * 48 + ch] = ((const GLOBAL_AS float *)pp->part[pt].bias)[pp->part[pt].ch0 + ch];
+            for (int j = 0; j < NF; ++j) wf[c][j] = *(const GLOBAL_AS s16x8 *)(wsrc + (c * NF + j) * 1024);
+        if (tid < nparts * CPP) {
+            const int pt = tid / CPP, ch = tid - pt * CPP;
+            bias_lds[pt * CPP + ch] = ((const GLOBAL_AS float *)pp->part[pt].bias)[pp->part[pt].ch0 + ch];
         }
     }
     const int cout = pp->part[part].cout, ch0 = pp->part[part].ch0, relu = pp->part[part].relu;
     GLOBAL_AS unsigned short *const out = (GLOBAL_AS unsigned short *)pp->part[part].out;
-    const float lo = relu ? 0.f : -INFINITY;   // ReLU as one v_max with a wave-uniform floor
+    const float lo = relu ? 0.f : -INFINITY;   // ReLU as one v_med3 with a wave-uniform floor
 
-    // per-lane LDS byte offset of k-group g of chunk c relative to the lane's own pixel slot (row 2*rr, plane 0, j = wo)
-    int xoff[NCH];
+    // LDS byte offset of k-group g of chunk c relative to the lane's own pixel slot (row 2*rr, plane 0, j = wo) in half 0.
+    // cin = 48: chunks straddle taps (48 = 1.5 chunks), one per-lane value per chunk.  cin = 96: a tap is three whole chunks,
+    // offset = tap shift (wave-uniform, computed from constants) + one of three per-lane values.
+    constexpr int NXO = CIN == 48 ? NCH : 3;
+    int xoff[NXO];
+    if constexpr (CIN == 48) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        int k0 = 32 * c + 8 * g;
-        if (k0 >= 9 * CIN) k0 = 0;   // zero weights: any valid slab address
-        const int tap = k0 / CIN, ci = k0 - tap * CIN;
-        const int dh = tap / 3, dw = tap - 3 * dh;
-        xoff[c] = (dh * slots_per_vrow + (dw & 1) * Wop + (dw >> 1)) * ROWB + ci * 2;
+        for (int c = 0; c < NCH; ++c) {
+            int k0 = 32 * c + 8 * g;
+            if (k0 >= 9 * CIN) k0 = 0;   // zero weights: any valid slab address
+            const int tap = k0 / CIN, ci = k0 - tap * CIN;
+            const int dh = tap / 3, dw = tap - 3 * dh;
+            xoff[c] = (dh * slots_per_vrow + (dw & 1) * Wop + (dw >> 1)) * ROWB + ci * 2;
+        }
+    } else {
+#pragma unroll
+        for (int sub = 0; sub < 3; ++sub) {
+            const int ci = 32 * sub + 8 * g;
+            xoff[sub] = (ci / 48) * HALF_BYTES + (ci % 48) * 2;
+        }
     }
+    auto chunk_off = [&](int c) -> unsigned {   // c is a compile-time constant at every call
+        if constexpr (CIN == 48) {
+            return (unsigned)xoff[c];
+        } else {
+            const int tap = c / 3, dh = tap / 3, dw = tap - 3 * dh;
+            return (unsigned)((dh * slots_per_vrow + (dw & 1) * Wop + (dw >> 1)) * ROWB) + (unsigned)xoff[c % 3];
+        }
+    };
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_s2;
 
     int nlast = 0;   // stores this wave issued AFTER its last LDS-DMA piece of the previous iteration (they may stay in flight)
@@ -155,6 +173,8 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (nlast == 2)
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (nlast == 1)
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -174,32 +194,32 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
         const int mf = (npx + 15) >> 4;
         const long q0 = (long)n * out_hpwp + (long)h0 * Wop;   // flat output row of the tile's first pixel
         if (active) {
-            for (int f0 = wf0; f0 < mf; f0 += 2 * wfs) {
-                const int f1 = f0 + wfs;
-                const bool two = f1 < mf;                 // wave-uniform
-                const bool last_pair = f0 + 2 * wfs >= mf;
-                int tp[2], wo[2];
-                unsigned xa[2];
+            for (int f0 = wf0; f0 < mf; f0 += MW * wfs) {
+                const bool last_iter = f0 + MW * wfs >= mf;     // wave-uniform
+                int nfr = 0;                                     // fragments of this iteration that exist (wave-uniform)
+                int tp[MW], wo[MW];
+                unsigned xa[MW];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    int tt = (i == 0 ? f0 : f1) * 16 + li;
+                for (int i = 0; i < MW; ++i) {
+                    if (f0 + i * wfs < mf) nfr = i + 1;
+                    int tt = (f0 + i * wfs) * 16 + li;
                     tp[i] = tt;
-                    if (tt >= npx) tt = 0;   // dead lanes / the missing second fragment: any valid pixel, never stored
+                    if (tt >= npx) tt = 0;   // dead lanes / a missing fragment: any valid pixel, never stored
                     const int rr = (int)(((unsigned long long)(unsigned)tt * magic_wop) >> shift_wop);
                     wo[i] = tt - rr * Wop;
                     xa[i] = lds0 + b * kS2SlabBytes + (2 * rr * slots_per_vrow + wo[i]) * ROWB;
                 }
-                f32x4 acc[2][3];
+                f32x4 acc[MW][NF];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MW; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 // pixel fragments are requested S2_DEPTH chunks ahead (ring of S2_DEPTH + 1 register sets)
-                s16x8 xf[S2_DEPTH + 1][2];
-#define S2_READ(SET, C)                                                                                   \
-    {                                                                                                     \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(xf[SET][0]) : "v"(xa[0] + (unsigned)xoff[C]));          \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(xf[SET][1]) : "v"(xa[1] + (unsigned)xoff[C]));          \
+                s16x8 xf[S2_DEPTH + 1][MW];
+#define S2_READ(SET, C)                                                                                         \
+    {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MW; ++i)                                                          \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xf[SET][i]) : "v"(xa[i] + chunk_off(C)));                 \
     }
 #pragma unroll
                 for (int c = 0; c < S2_DEPTH; ++c) S2_READ(c, c)
@@ -208,18 +228,17 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
                     const int cur = c % (S2_DEPTH + 1);
                     if (c + S2_DEPTH < NCH) {
                         S2_READ((c + S2_DEPTH) % (S2_DEPTH + 1), c + S2_DEPTH)
-                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(2 * S2_DEPTH) : "memory");   // chunk c landed, the next ones in flight
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(MW * S2_DEPTH) : "memory");   // chunk c landed, the next ones in flight
                     } else {
-                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(2 * (NCH - 1 - c)) : "memory");
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(MW * (NCH - 1 - c)) : "memory");
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c][j]),
-                                                                            __builtin_bit_cast(bf16x8, xf[cur][0]), acc[0][j], 0, 0, 0);
-                        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c][j]),
-                                                                            __builtin_bit_cast(bf16x8, xf[cur][1]), acc[1][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < NF; ++j)
+#pragma unroll
+                        for (int i = 0; i < MW; ++i)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c][j]),
+                                                                                __builtin_bit_cast(bf16x8, xf[cur][i]), acc[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if ((c & 1) && pk < NSP) {   // one LDS-DMA piece every other chunk
                         piece(nx, pk);
@@ -227,45 +246,56 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
                     }
                 }
 #undef S2_READ
-                if (last_pair) {  // whatever is left of the next slab goes out BEFORE this wave's last stores (counted wait above)
+                if (last_iter) {  // whatever is left of the next slab goes out BEFORE this wave's last stores (counted wait above)
                     for (; pk < NSP; ++pk) piece(nx, pk);
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);   // the stores below stay below: they are what the counted wait leaves in flight
                 }
-                // ---- epilogue: + bias, ReLU, zero at the pad column; a lane owns 12 contiguous channels of one pixel
-                const float *bl = bias_lds + part * 48 + g * 12;
-                const f32x4 b0 = *(const f32x4 *)(bl), b1 = *(const f32x4 *)(bl + 4), b2 = *(const f32x4 *)(bl + 8);
+                // ---- epilogue: + bias, ReLU, zero at the pad column; a lane owns 4*NF contiguous channels of one pixel
+                const float *bl = bias_lds + part * CPP + g * 4 * NF;
+                f32x4 bs[NF];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (i == 1 && !two) break;
+                for (int j = 0; j < NF; ++j) bs[j] = *(const f32x4 *)(bl + 4 * j);
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    if (i >= nfr) break;
                     if (tp[i] < npx) {
                         const float hi = wo[i] < Wo ? INFINITY : 0.f;   // pad column: clamp to [0, 0]
                         const float lo_i = wo[i] < Wo ? lo : 0.f;
-                        float v[12];
+                        unsigned pk2[2 * NF];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            v[r] = acc[i][0][r] + b0[r];
-                            v[4 + r] = acc[i][1][r] + b1[r];
-                            v[8 + r] = acc[i][2][r] + b2[r];
-                        }
-                        unsigned pk2[6];
+                        for (int j = 0; j < NF; ++j)
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) {
-                            float a0, a1;
-                            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(a0) : "v"(v[2 * r]), "v"(lo_i), "v"(hi));
-                            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(a1) : "v"(v[2 * r + 1]), "v"(lo_i), "v"(hi));
-                            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk2[r]) : "v"(a0), "v"(a1));
-                        }
-                        GLOBAL_AS unsigned short *o = out + (size_t)(q0 + tp[i]) * cout + ch0 + g * 12;
+                            for (int h = 0; h < 2; ++h) {
+                                float a0 = acc[i][j][2 * h] + bs[j][2 * h], a1 = acc[i][j][2 * h + 1] + bs[j][2 * h + 1];
+                                asm("v_med3_f32 %0, %1, %2, %3" : "=v"(a0) : "v"(a0), "v"(lo_i), "v"(hi));
+                                asm("v_med3_f32 %0, %1, %2, %3" : "=v"(a1) : "v"(a1), "v"(lo_i), "v"(hi));
+                                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk2[2 * j + h]) : "v"(a0), "v"(a1));
+                            }
+                        GLOBAL_AS unsigned short *o = out + (size_t)(q0 + tp[i]) * cout + ch0 + g * 4 * NF;
                         *(GLOBAL_AS u32x4 *)o = u32x4{pk2[0], pk2[1], pk2[2], pk2[3]};
-                        *(GLOBAL_AS u32x2 *)(o + 8) = u32x2{pk2[4], pk2[5]};
+                        if constexpr (NF == 3) *(GLOBAL_AS u32x2 *)(o + 8) = u32x2{pk2[4], pk2[5]};
                     }
                 }
-                if (last_pair) nlast = __builtin_amdgcn_readfirstlane(two ? 4 : 2);
+                if (last_iter) nlast = __builtin_amdgcn_readfirstlane(nfr * (NF == 3 ? 2 : 1));
             }
         }
         for (; pk < NSP; ++pk) piece(nx, pk);   // waves without fragments in this tile (and inactive ones)
     }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__restrict__ probs, const int2 *__restrict__ map) {
+    extern __shared__ __attribute__((aligned(1024))) char smem_s2[];
+    const int2 e = map[blockIdx.x];
+    const int prob = __builtin_amdgcn_readfirstlane(e.x & 0xff), ntile = __builtin_amdgcn_readfirstlane(e.x >> 8);
+    const int tile0 = __builtin_amdgcn_readfirstlane(e.y);
+    const GLOBAL_AS S2Problem *pp = (const GLOBAL_AS S2Problem *)(probs + prob);
+    // <96, 2, 1> (27 chunks x 2 fragments = 216 weight VGPRs) compiles, but needs ~280 registers with everything else and
+    // spills 24 of them into scratch -- whose accesses are vector-memory operations in the middle of the counted waits: the
+    // 96-input-channel convolutions stay on the generic kernel (hrnet_mi355.cpp: ConvOp::s2 only for cin == 48)
+    s2_run<48, 3, 2>(pp, ntile, tile0, smem_s2);
 }
 
 hipError_t launch_conv_s2(const S2Problem *probs_dev, const void *map_dev, int nblocks, hipStream_t s) {

@@ -304,8 +304,8 @@ struct hrn_ctx {
 
     // output rows per tile of the stride-2 slab kernel: as many as one slab buffer holds ((2R + 1) virtual input rows of
     // 2 * wop slots of 96 bytes)
-    static int s2_rows(int wop, int ho) {
-        const int vrows = kS2SlabBytes / (2 * wop * 96);
+    static int s2_rows(int wop, int ho, int cin) {
+        const int vrows = kS2SlabBytes / (2 * wop * cin * 2);
         int r = (vrows - 1) / 2;
         return r > ho ? ho : r;
     }
@@ -353,8 +353,8 @@ struct hrn_ctx {
             op.slices = op.cin / 16, op.ntiles = cout / (16 * op.nr), op.nch = 9;
             op.kpad = 9 * 16 * op.slices;
         }
-        if (dtype == HRN_BF16 && k == 3 && stride == 2 && op.cin == 48 && cout % 48 == 0 && !up && !disable_s2 && op.algo == 0 &&
-            s2_rows(ow + 1, oh) >= 1)
+        if (dtype == HRN_BF16 && k == 3 && stride == 2 && op.cin == 48 &&   // (cin = 96 does not fit the registers: conv_s2.hip)
+            cout % (16 * s2_frags_per_part(op.cin)) == 0 && !up && !disable_s2 && op.algo == 0 && s2_rows(ow + 1, oh, op.cin) >= 1)
             op.s2 = true;
         convs.push_back(op);
         if (emit) emit_convs({(int)convs.size() - 1});
@@ -412,7 +412,7 @@ struct hrn_ctx {
             g.conv_idx = s2;
             for (int i : s2) {
                 const ConvOp &cv = convs[i];
-                for (int t = 0; t < cv.cout / 48; ++t) {
+                for (int t = 0; t < cv.cout / (16 * s2_frags_per_part(cv.cin)); ++t) {
                     S2Group::Prob *pr = nullptr;
                     for (auto &q : g.probs)
                         if (q.in_t == cv.in_t && (int)q.parts.size() < kS2MaxParts) pr = &q;
@@ -421,7 +421,7 @@ struct hrn_ctx {
                         pr = &g.probs.back();
                         pr->in_t = cv.in_t;
                         const Tensor &to = tensors[cv.out_t];
-                        pr->rows = s2_rows(to.wp, to.h);
+                        pr->rows = s2_rows(to.wp, to.h, cv.cin);
                         pr->tiles_per_image = (to.h + pr->rows - 1) / pr->rows;
                     }
                     pr->parts.push_back({i, t});
@@ -758,9 +758,10 @@ struct hrn_ctx {
             off = align_up(off + cv.w_bytes, 256);
             cv.b_off = off;
             off = align_up(off + cv.cout * 4, 256);
-            if (cv.s2) {  // the (48, 3) LDS image for the slab kernel: [cout tile][14 chunks][3 frags][64 lanes][16 B]
+            if (cv.s2) {  // the slab kernel's image: [cout tile][K chunks][frags][64 lanes][16 B], (48, 3): 14 chunks, (96, 2): 27
+                const int nf = s2_frags_per_part(cv.cin);
                 cv.w2_off = off;
-                cv.w2_bytes = (int64_t)(cv.cout / 48) * 14 * 3 * 1024;
+                cv.w2_bytes = (int64_t)(cv.cout / (16 * nf)) * ((9 * cv.cin + 31) / 32) * nf * 1024;
                 off = align_up(off + cv.w2_bytes, 256);
             }
         }
@@ -1032,7 +1033,8 @@ struct hrn_ctx {
             const Tensor &to = tensors[convs[pr.parts[0].first].out_t];
             const int frags = (pr.rows * to.wp + 15) / 16;
             const int wm = std::max(1, 8 / (int)pr.parts.size());     // fewest waves sharing a part
-            cost[k] = (double)((frags + wm - 1) / wm) * 14 * 3 + 60;   // MFMAs of the busiest wave + per-tile overhead
+            const int cin = convs[pr.parts[0].first].cin;
+            cost[k] = (double)((frags + wm - 1) / wm) * ((9 * cin + 31) / 32) * s2_frags_per_part(cin) + 60;   // MFMAs of the busiest wave + per-tile overhead
             total += cost[k] * nb * pr.tiles_per_image;
         }
         const double per_block = total / s2_target_blocks;
@@ -1091,7 +1093,7 @@ struct hrn_ctx {
                 const Tensor &ti = tensors[pr.in_t], &to = tensors[convs[pr.parts[0].first].out_t];
                 S2Problem &q = hp[g.prob_first + k];
                 memset(&q, 0, sizeof q);
-                q.in = row0(pr.in_t), q.in_wp = ti.wp, q.in_hpwp = ti.hpwp;
+                q.in = row0(pr.in_t), q.cin = ti.c, q.in_wp = ti.wp, q.in_hpwp = ti.hpwp;
                 q.ho = to.h, q.wo = to.w, q.wop = to.wp, q.out_hpwp = to.hpwp;
                 q.rows = pr.rows, q.tiles_per_image = pr.tiles_per_image;
                 q.nparts = (int)pr.parts.size();
@@ -1100,10 +1102,11 @@ struct hrn_ctx {
                 for (int i = 0; i < q.nparts; ++i) {
                     const ConvOp &cv = convs[pr.parts[i].first];
                     S2Part &pt = q.part[i];
-                    pt.w = blob + cv.w2_off + (int64_t)pr.parts[i].second * 14 * 3 * 1024;
+                    const int nf = s2_frags_per_part(cv.cin);
+                    pt.w = blob + cv.w2_off + (int64_t)pr.parts[i].second * ((9 * cv.cin + 31) / 32) * nf * 1024;
                     pt.bias = (const float *)(blob + cv.b_off);
                     pt.out = row0(cv.out_t);
-                    pt.cout = cv.cout, pt.ch0 = pr.parts[i].second * 48, pt.relu = cv.relu;
+                    pt.cout = cv.cout, pt.ch0 = pr.parts[i].second * 16 * nf, pt.relu = cv.relu;
                 }
             }
             g.map_capacity = 64;
@@ -1395,8 +1398,9 @@ struct hrn_ctx {
             else
                 pack_conv(cv, wf.data(), K, host.data() + cv.w_off);
             if (cv.s2) {
-                ConvOp img = cv;   // same folded weights in the (48, 3) slice-major form
-                img.ks = 48, img.nr = 3, img.slices = 1, img.ntiles = cv.cout / 48, img.nch = 14, img.n96 = false;
+                ConvOp img = cv;   // same folded weights as ONE slice of all cin channels: k = tap * cin + ci, as the generic kernel orders it
+                img.ks = cv.cin, img.nr = s2_frags_per_part(cv.cin), img.slices = 1, img.ntiles = cv.cout / (16 * img.nr);
+                img.nch = (9 * cv.cin + 31) / 32, img.n96 = false;
                 pack_conv_lds(img, wf.data(), K, host.data() + cv.w2_off);
             }
             float *db = (float *)(host.data() + cv.b_off);

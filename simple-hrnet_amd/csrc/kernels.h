@@ -64,25 +64,27 @@ int conv3x3_lds_bm(int ks, int nrb, int wp);  // (32, 6) = the 96-cout form; ks 
 int conv3x3_f32_bm(int wp);
 hipError_t launch_conv3x3_f32(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb, int nrb, hipStream_t s);
 
-// Stride-2 slab kernel (conv_s2.hip): every 3x3 / stride-2 convolution with 48 input channels that reads ONE tensor at one
-// fuse level is a "part" (48 output channels each) of one problem; a block stages the input slab of `rows` output rows once
-// and its waves keep the parts' weights in registers.
-constexpr int kS2SlabBytes = 79872;   // one slab buffer: 832 slots of 96 bytes (two of them + the biases fill the 160 KiB)
+// Stride-2 slab kernel (conv_s2.hip): every 3x3 / stride-2 convolution with 48 (or 96) input channels that reads ONE tensor at
+// one fuse level contributes "parts" (48 (32) output channels each) to one problem; a block stages the input slab of `rows`
+// output rows once and its waves keep the parts' weights in registers.
+constexpr int kS2SlabBytes = 79872;   // one slab buffer: 832 sub-slots of 96 bytes (two of them + the biases fill the 160 KiB)
+inline int s2_frags_per_part(int cin) { return cin == 48 ? 3 : 2; }   // 16-cout fragments a wave keeps in registers
 constexpr int kS2MaxParts = 8;
 struct S2Part {
-    const void *w;      // [14 chunks][3 frags][64 lanes][16 B]: the (48, 3) image of pack_conv_lds for this 48-cout tile
+    const void *w;      // [K chunks][frags][64 lanes][16 B]: the (cin, frags) image of pack_conv_lds for this cout tile (k = tap * cin + ci)
     const float *bias;  // the convolution's folded bias (indexed with ch0 + c)
     void *out;          // row 0 of the convolution's output tensor
     int cout, ch0;      // channels per row of that tensor, first channel of this part
     int relu, pad_;
 };
 struct S2Problem {
-    const void *in;     // row 0 of the input tensor (48 channels)
+    const void *in;     // row 0 of the input tensor
+    int cin;            // 48 or 96
     int in_wp, in_hpwp;
     int ho, wo, wop, out_hpwp;   // output geometry (shared by all parts)
     int rows;                    // output rows per tile
     int tiles_per_image;         // ceil(ho / rows)
-    int nparts;                  // cout groups of 48
+    int nparts;                  // cout groups (of 16 * s2_frags_per_part(cin) channels)
     // wave w works on part wave_part[w] (0xff: idle) and on the pixel fragments wave_f0[w], + wave_fs[w], ... of every tile
     unsigned char wave_part[8], wave_f0[8], wave_fs[8];
     unsigned magic_wop;          // x / wop == (x * magic) >> shift
