@@ -74,7 +74,7 @@ def test_s2_block_map_covers_every_tile_once(c, h, w, mb):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("h,w,n", [(384, 288, 3), (256, 192, 5), (128, 96, 4), (64, 64, 2), (320, 224, 2)])
+@pytest.mark.parametrize("h,w,n", [(384, 288, 3), (256, 192, 5), (128, 96, 4), (64, 64, 2), (320, 224, 2), (512, 384, 2), (96, 160, 3), (32, 32, 7)])
 def test_s2_kernel_on_off_is_bit_identical(monkeypatch, h, w, n):
     """HRN_S2_MIN_TILES=1 forces the slab kernel at any batch size; HRN_DISABLE_S2 routes the same convolutions to the
     generic kernel.  Same K order, same MFMA operand layout, bias added last in both: identical bits."""
