@@ -424,3 +424,69 @@ class EngineEmulation:
 def hrnet_forward_engine(sd: Dict, images, round_weights: bool = True, round_acts: bool = True, taps=None):
     """-> heat-maps (n,J,h,w) fp32, or (heat-maps, {tap name: tensor}) when ``taps`` is given."""
     return EngineEmulation(sd, round_weights, round_acts).forward(images, taps)
+
+
+class PoseResNetEmulation(EngineEmulation):
+    """The same engine-arithmetic restatement for the other model of the selector (models_/poseresnet.py:16-122; restated in
+    fp32 by ``poseresnet_forward`` above, which is pinned to the reference fixture): 7x7 stem, max-pool, Bottleneck layers
+    (stride in conv2, projection shortcut in the first block of a layer), three ConvTranspose2d(4, s2, p1) + BN + ReLU, head.
+    Node names = the engine's taps: "stem", "maxpool", "<layer>.<block>.conv1..3", "<layer>.<block>.downsample.0",
+    "deconv_layers.0 / 3 / 6" (the transposed convolution; its BatchNorm is deconv_layers.1 / 4 / 7)."""
+
+    def __init__(self, sd: Dict, resnet_size: int = 50, round_weights: bool = True, round_acts: bool = True):
+        self.size = resnet_size
+        super().__init__(sd, round_weights, round_acts)
+
+    def _build(self):
+        x = self._node("stem", op="stem7", x=self.INPUT)
+        x = self._node("maxpool", op="maxpool", x=x)
+        for li, blocks in enumerate(RESNET_LAYERS[self.size]):
+            for b in range(blocks):
+                p = "layer%d.%d" % (li + 1, b)
+                stride = 2 if (b == 0 and li > 0) else 1
+                o = self._conv(p + ".conv1", p + ".bn1", x)
+                o = self._conv(p + ".conv2", p + ".bn2", o, stride=stride)
+                r = x
+                if b == 0:
+                    r = self._conv(p + ".downsample.0", p + ".downsample.1", x, stride=stride, relu=False)
+                x = self._conv(p + ".conv3", p + ".bn3", o, res=r)
+        for i in range(3):
+            x = self._node("deconv_layers.%d" % (3 * i), op="deconv", bn="deconv_layers.%d" % (3 * i + 1), x=x)
+        self._node(self.HEAD, op="head", x=x)
+
+    @torch.no_grad()
+    def eval_node(self, name, vals, magnitude: bool = False):
+        nd = self.graph[name]
+        if nd["op"] not in ("stem7", "maxpool", "deconv"):
+            return super().eval_node(name, vals, magnitude)
+        mag = None
+        if nd["op"] == "stem7":
+            x = vals[nd["x"]].to(torch.float32)
+            if self.ra:
+                x = _bf16r(x)
+            w, b = self._fold("conv1", "bn1")
+            y = self._store(F.relu(F.conv2d(x, w, b, stride=2, padding=3)))
+            if magnitude:
+                mag = F.conv2d(x.abs(), w.abs(), b.abs(), stride=2, padding=3)
+        elif nd["op"] == "maxpool":
+            y = F.max_pool2d(vals[nd["x"]], 3, 2, 1)   # values are stored bf16 already: the maximum of stored values
+            if magnitude:
+                mag = y.abs()
+        else:  # ConvTranspose2d(cin, cout, 4, 2, 1) weight [ci][co][ky][kx] + BatchNorm over co + ReLU
+            key = name
+            if key not in self._folded:
+                w = _t(self.sd, name + ".weight").to(torch.float64)
+                bn = nd["bn"]
+                g, b = _t(self.sd, bn + ".weight").to(torch.float64), _t(self.sd, bn + ".bias").to(torch.float64)
+                mu, var = _t(self.sd, bn + ".running_mean").to(torch.float64), _t(self.sd, bn + ".running_var").to(torch.float64)
+                scale = g / torch.sqrt(var + 1e-5)
+                wf = (w * scale.view(1, -1, 1, 1)).to(torch.float32)
+                if self.rw:
+                    wf = _bf16r(wf)
+                self._folded[key] = (wf, (b - mu * scale).to(torch.float32))
+            w, b = self._folded[key]
+            x = vals[nd["x"]]
+            y = self._store(F.relu(F.conv_transpose2d(x, w, b, 2, 1, 0)))
+            if magnitude:
+                mag = F.conv_transpose2d(x.abs(), w.abs(), b.abs(), 2, 1, 0)
+        return (y, mag) if magnitude else y

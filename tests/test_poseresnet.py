@@ -96,3 +96,37 @@ def test_gpu_bf16_bounded_and_other_shapes():
     np.testing.assert_allclose(hm.cpu().numpy(), ref, rtol=0, atol=2e-5)
     np.testing.assert_array_equal(pts.cpu().numpy()[..., :2], T.decode_heatmaps(ref, boxes)[..., :2])
     net.close()
+
+
+def test_engine_emulation_without_rounding_is_the_pinned_oracle():
+    """oracle/hrnet_torch_oracle.py: PoseResNetEmulation (what the bf16 PoseResNet kernels are pinned to, operation by operation)
+    with its roundings off against the reference fixture and the fp32 restatement, and its node names against the plan's taps"""
+    g = golden(NAME)
+    pkg = load_pkg()
+    c = int(g["c"])
+    sd = pkg.synth.to_torch_state_dict(_sd(pkg, c, int(g["weight_seed"])))
+    hm = T.PoseResNetEmulation(sd, c, round_weights=False, round_acts=False).forward(torch.from_numpy(g["crops"])).numpy()
+    np.testing.assert_allclose(hm, g["heatmaps"], rtol=0, atol=2e-6)
+    emu = T.PoseResNetEmulation(sd, c)
+    net = pkg.NativeHRNet(c, 17, (int(g["h"]), int(g["w"])), "bf16", max_batch=2, device=-1, model_name="PoseResNet")
+    taps = {t.name.decode() for t in net.tap_infos()}
+    assert set(emu.order) - {emu.HEAD} - taps == {"layer1.0.downsample.0"} and taps <= set(emu.order)
+    net.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,h,w,n", [(50, 128, 96, 2), (50, 256, 192, 33), (101, 128, 96, 1)])
+def test_gpu_bf16_every_operation_meets_the_emulation(size, h, w, n):
+    """the bf16 PoseResNet path -- 7x7 MFMA stem, max-pool, the Bottleneck convolutions (chain kernel in layer1, LDS-staged 3x3s,
+    stride-2 1x1 projections), the four-phase transposed convolutions, the MFMA head -- operation by operation on the engine's
+    own stored inputs, as tests/test_bf16_pin.py does for HRNet"""
+    from test_bf16_pin import Pinner
+    pkg = load_pkg()
+    sd_np = _sd(pkg, size, 7)
+    emu = T.PoseResNetEmulation(pkg.synth.to_torch_state_dict(sd_np), size)
+    net = pkg.NativeHRNet(size, 17, (h, w), "bf16", max_batch=n, device=0, model_name="PoseResNet").load_state_dict(sd_np)
+    x = torch.from_numpy(pkg.synth_crops(n, h, w, seed=29)).cuda()
+    pin = Pinner(pkg, net, emu, x, crop0=0, ncrops=min(n, 2), crop_step=max(1, n - 1))
+    pin.check_all()
+    pin.report("PoseResNet-%d %dx%d n=%d" % (size, h, w, n))
+    net.close()
