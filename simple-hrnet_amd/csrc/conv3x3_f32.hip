@@ -7,7 +7,8 @@
 // 16-byte fragment per lane = FOUR 16x16x4 MFMAs (lane (li, g) holds k = 4g + t of its row for t = 0..3).  What differs is
 // the balance: an fp32 fragment pair keeps the matrix pipe busy for 4 x 32 cycles against 16 for bf16, so LDS reads, LDS-DMA
 // and the per-slice barrier are a few per cent of the MFMA time and a plain two-buffer pipeline (next slice's slab + weights
-// requested at the top of a stage, vmcnt(0) + barrier at its end) is enough: no hand-issued reads, no counted waits.
+// requested one LDS-DMA piece per K chunk during a stage, vmcnt(0) + barrier at its end, fragments read one chunk ahead) is
+// enough: no hand-issued reads, no counted waits.
 // The generic kernel this replaces for these convolutions (conv_direct_kernel<DT_F32>) fetches every fragment from L2 and
 // lives on occupancy: 0.35 of the 157 TF fp32 MFMA peak on configs[1] (BENCH_r02).
 // K order: slice-major, tap, channel (the generic kernel: tap-major) -- so a convolution takes this form at EVERY batch
@@ -75,22 +76,43 @@ __device__ __forceinline__ void c3f_run(const Conv3Problem &p, const int nt, con
     const GLOBAL_AS float *const res = (const GLOBAL_AS float *)p.res;
     const GLOBAL_AS char *const wsrc_nt = (const GLOBAL_AS char *)p.w + (size_t)nt * S * WSL;
 
-    // stage (tile tt, slice s) -> buffers b: the (cout tile, s) weights and the slab of channels [16 s, 16 s + 16)
-    auto issue = [&](int tt, int s, int b) {
-        const GLOBAL_AS char *wsrc = wsrc_nt + (size_t)s * WSL;
-#pragma unroll
-        for (int k = 0; k < NWP; ++k) {
-            const int u0 = k * F_NT + wave * 64;
-            if (u0 < WSL / 16) glds16(wsrc + (size_t)(u0 + lane) * 16, wbuf + b * WSL + u0 * 16);
-        }
-        const long row0 = (long)(mt0 + tt) * BM - p.wp - 1;   // guard rows make negative / overrun rows valid
-        const GLOBAL_AS char *ssrc = (const GLOBAL_AS char *)(in + row0 * p.cin + s * 16);
-#pragma unroll
-        for (int k = 0; k < F_NSP; ++k)
-            if (k * F_NT + wave * 64 < slab_units) glds16(ssrc + srel[k], sbuf + b * F_SLAB + (k * F_NT + wave * 64) * 16);
+    // stage (tile tt, slice s) -> buffers b: the (cout tile, s) weights and the slab of channels [16 s, 16 s + 16), as
+    // NWP + F_NSP one-KiB LDS-DMA pieces per wave.  A piece costs its wave ~150 issue cycles, so they go out one per K chunk
+    // under the MFMAs of the stage that runs meanwhile (all at once at the stage top, both waves of every SIMD sit in DMA issue
+    // together: measured 1.5 % slower)
+    struct Stage {
+        const GLOBAL_AS char *wsrc, *ssrc;
+        char *wdst, *sdst;
+        bool on;
     };
+    auto plan = [&](int tt, int s, int b) {
+        Stage st;
+        st.on = true;
+        st.wsrc = wsrc_nt + (size_t)s * WSL;
+        st.wdst = wbuf + b * WSL;
+        const long row0 = (long)(mt0 + tt) * BM - p.wp - 1;   // guard rows make negative / overrun rows valid
+        st.ssrc = (const GLOBAL_AS char *)(in + row0 * p.cin + s * 16);
+        st.sdst = sbuf + b * F_SLAB;
+        return st;
+    };
+    auto piece = [&](const Stage &st, int k) {
+        if (!st.on) return;
+        if (k < NWP) {
+            const int u0 = k * F_NT + wave * 64;
+            if (u0 < WSL / 16) glds16(st.wsrc + (size_t)(u0 + lane) * 16, st.wdst + u0 * 16);
+        } else {
+            const int ks = k - NWP;
+            if (ks * F_NT + wave * 64 < slab_units) glds16(st.ssrc + srel[ks], st.sdst + (ks * F_NT + wave * 64) * 16);
+        }
+    };
+    constexpr int NPIECE = NWP + F_NSP;
+    static_assert(NPIECE <= 2 * F_NCH, "at most two LDS-DMA pieces per chunk");
 
-    issue(0, 0, 0);
+    {
+        const Stage s0 = plan(0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NPIECE; ++k) piece(s0, k);
+    }
     f32x4 acc[MR][NRB];
     int st = 0;
     for (int tt = 0; tt < ntile; ++tt) {
@@ -100,30 +122,40 @@ __device__ __forceinline__ void c3f_run(const Conv3Problem &p, const int nt, con
             for (int j = 0; j < NRB; ++j) acc[i][j] = bias[j];   // accumulators start at the folded-BN bias
         for (int s = 0; s < S; ++s, ++st) {
             const int b = st & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's pieces (issued a whole stage ago) have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's pieces (issued during the previous stage) have landed
             __syncthreads();                                    // everybody's have; everybody is done with the other buffers
+            Stage nx;
+            nx.on = false, nx.wsrc = wsrc_nt, nx.ssrc = (const GLOBAL_AS char *)in, nx.wdst = wbuf, nx.sdst = sbuf;
             {
                 int s2 = s + 1, t2 = tt;
                 if (s2 == S) s2 = 0, ++t2;
-                if (t2 < ntile) issue(t2, s2, b ^ 1);
+                if (t2 < ntile) nx = plan(t2, s2, b ^ 1);
             }
             const char *wl = wbuf + b * WSL + lane * 16;
             const char *xl = sbuf + b * F_SLAB + xrow0;
+            // fragments one chunk ahead (two register sets)
+            f32x4 wf[2][NRB], xf[2][MR];
+#define C3F_READ(SET, C)                                                                              \
+    {                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NRB; ++j) wf[SET][j] = *(const f32x4 *)(wl + ((C)*NRB + j) * 1024); \
+        _Pragma("unroll") for (int i = 0; i < MR; ++i) xf[SET][i] = *(const f32x4 *)(xl + xoff[C] + i * 16 * F_ROWB); \
+    }
+            C3F_READ(0, 0)
 #pragma unroll
             for (int c = 0; c < F_NCH; ++c) {
-                f32x4 wf[NRB], xf[MR];
-#pragma unroll
-                for (int j = 0; j < NRB; ++j) wf[j] = *(const f32x4 *)(wl + (c * NRB + j) * 1024);
-#pragma unroll
-                for (int i = 0; i < MR; ++i) xf[i] = *(const f32x4 *)(xl + xoff[c] + i * 16 * F_ROWB);
+                const int cur = c & 1;
+                if (c + 1 < F_NCH) C3F_READ(cur ^ 1, c + 1)
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int i = 0; i < MR; ++i)
 #pragma unroll
                         for (int j = 0; j < NRB; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][t], xf[i][t], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cur][j][t], xf[cur][i][t], acc[i][j], 0, 0, 0);
+                piece(nx, c);
+                if (c + F_NCH < NPIECE) piece(nx, c + F_NCH);
             }
+#undef C3F_READ
         }
         // ---- epilogue: (+ residual) (ReLU), zero on pad pixels; a lane owns 4*NRB contiguous channels of one pixel
         const int p0 = (mt0 + tt) * BM;
