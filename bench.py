@@ -329,32 +329,28 @@ def clip_measure(pkg, net, dist, rank, world, cpu_clip=None):
             ref = pts
         elif mode == "per_frame_sync" and ref is not None:
             res["per_frame_sync"]["same_joints_as_per_frame"] = bool(np.array_equal(pts, ref))
-    # several frames in flight: L small engines (max_batch = people per frame) sharing the GPU, weights copied blob to blob
-    try:
-        lanes = int(os.environ.get("HRN_CLIP_LANES", "3"))
-        smalls = [pkg.NativeHRNet(net.c, net.nof_joints, net.resolution, net.dtype, max_batch=int(dets.shape[1]), device=net.device_index,
-                                  model_name=net.model_name) for _ in range(lanes)]
-        for sm in smalls:
-            sm.weight_blob_tensor().copy_(net.weight_blob_tensor())
-            torch.cuda.synchronize(net.torch_device)
-            sm.adopt_weights()
-        streams = [torch.cuda.Stream(net.torch_device) for _ in range(lanes)]
-        run_clip_pipelined(smalls, streams, clip_host, dets, rank, world)
-        if dist:
-            dist.barrier()
-        pts, el = run_clip_pipelined(smalls, streams, clip_host, dets, rank, world)
-        if dist:
-            t = torch.tensor([el], device=net.torch_device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        res["per_frame_pipelined"] = {"fps": round(clip.shape[0] / el, 2), "persons_per_s": round(dets.shape[0] * dets.shape[1] / el, 1),
-                                      "ms_per_frame": round(el / clip.shape[0] * 1e3, 3), "frames_in_flight": lanes,
-                                      "same_joints_as_per_frame": bool(ref is not None and np.array_equal(pts, ref)),
-                                      "note": "throughput with %d frames in flight on %d engines of one GPU; the latency of a frame is per_frame's" % (lanes, lanes)}
-        for sm in smalls:
-            sm.close()
-    except Exception as e:   # a side measurement: never lose the main ones to it
-        res["per_frame_pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # several frames in flight: L small engines (max_batch = people per frame) sharing the GPU, weights copied blob to blob.
+    # A single-GPU side measurement (no collectives inside the try: a rank that failed here must not leave the others at a barrier)
+    if world == 1:
+        try:
+            lanes = int(os.environ.get("HRN_CLIP_LANES", "3"))
+            smalls = [pkg.NativeHRNet(net.c, net.nof_joints, net.resolution, net.dtype, max_batch=int(dets.shape[1]), device=net.device_index,
+                                      model_name=net.model_name) for _ in range(lanes)]
+            for sm in smalls:
+                sm.weight_blob_tensor().copy_(net.weight_blob_tensor())
+                torch.cuda.synchronize(net.torch_device)
+                sm.adopt_weights()
+            streams = [torch.cuda.Stream(net.torch_device) for _ in range(lanes)]
+            run_clip_pipelined(smalls, streams, clip_host, dets)
+            pts, el = run_clip_pipelined(smalls, streams, clip_host, dets)
+            res["per_frame_pipelined"] = {"fps": round(clip.shape[0] / el, 2), "persons_per_s": round(dets.shape[0] * dets.shape[1] / el, 1),
+                                          "ms_per_frame": round(el / clip.shape[0] * 1e3, 3), "frames_in_flight": lanes,
+                                          "same_joints_as_per_frame": bool(ref is not None and np.array_equal(pts, ref)),
+                                          "note": "throughput with %d frames in flight on %d engines of one GPU; the latency of a frame is per_frame's" % (lanes, lanes)}
+            for sm in smalls:
+                sm.close()
+        except Exception as e:   # a side measurement: never lose the main ones to it
+            res["per_frame_pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
     res["fps"] = res["per_frame"]["fps"]
     if cpu_clip and "fps" in cpu_clip and rank == 0:
         res["cpu_reference_loop"] = {k: cpu_clip[k] for k in ("fps", "persons_per_s", "frames", "sample")}
