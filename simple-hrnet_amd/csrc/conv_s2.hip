@@ -1,5 +1,5 @@
-// 3x3 / stride-2 / pad-1 convolutions with 48 input channels (the first convs of HRNet-W48's fuse-down chains and the
-// chain convs that follow them, models_/hrnet.py:36-51) as an LDS-staged implicit GEMM on bf16 MFMA, written for gfx950.
+// 3x3 / stride-2 / pad-1 convolutions with 48 (HRNet-W48, branch 0) or 32 / 64 (HRNet-W32, branches 0 / 1) input channels: the
+// first convs of the fuse-down chains and the chain convs that follow them (models_/hrnet.py:36-51) as an LDS-staged implicit GEMM on bf16 MFMA, written for gfx950.
 //
 // Why its own kernel (DESIGN.md §5 "stride-2 slab kernel"): a stride-2 tile touches FOUR input pixels per output pixel and
 // the 16 pixels of an MFMA fragment sit two input columns apart, so neither the stride-1 kernel's slab (one contiguous run
@@ -50,13 +50,16 @@ __device__ __forceinline__ void glds16(const GLOBAL_AS void *gsrc, char *lds_wav
 //               the whole 32 x 864 weight matrix of a part stay in registers
 template <int CIN, int NF, int MW>
 __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int ntile, const int tile0, char *smem_s2) {
-    constexpr int HALVES = CIN / 48, ROWB = 96, UPR = 6;            // 96-byte sub-slots of 6 sixteen-byte units
+    // A slot (one input pixel, CIN * 2 bytes) lives in LDS as HALVES sub-slots of ROWB bytes in separate regions, so that the
+    // 16 consecutive pixels of a fragment read are ROWB bytes apart: 96 bytes (cin = 48, 96) or 32 bytes (cin = 32, 64) -- both
+    // put the eight lanes of an LDS phase on disjoint banks; 64 or 128 bytes would be 2- / 4-way conflicts.
+    constexpr int ROWB = s2_subslot_bytes(CIN), HALVES = CIN * 2 / ROWB, UPR = ROWB / 16;
     constexpr int NCH = (9 * CIN + 31) / 32;                         // K chunks of 32 (cin = 48: the last one half zero)
-    constexpr int HALF_BYTES = kS2SlabBytes / HALVES;                // LDS region of one channel half within a slab buffer
-    constexpr int NSPH = (HALF_BYTES / 16 + NT - 1) / NT;            // LDS-DMA pieces per thread and half
+    constexpr int HALF_BYTES = s2_region_bytes(CIN);                 // LDS region of one sub-slot plane within a slab buffer
+    constexpr int NSPH = (HALF_BYTES / 16 + NT - 1) / NT;            // LDS-DMA pieces per thread and region
     constexpr int NSP = NSPH * HALVES;
     constexpr int CPP = 16 * NF;                                     // couts per part
-    static_assert(HALF_BYTES % 1024 == 0, "a half starts on a whole LDS-DMA piece");
+    static_assert(HALF_BYTES % 1024 == 0 && HALF_BYTES * HALVES <= kS2SlabBytes, "a region is whole LDS-DMA pieces");
     // the descriptor's fields as scalars, once (a field read through a pointer is re-loaded after every "memory" clobber)
     const int in_wp = pp->in_wp, in_hpwp = pp->in_hpwp, Ho = pp->ho, Wo = pp->wo, Wop = pp->wop, out_hpwp = pp->out_hpwp;
     const int R = pp->rows, tpi = pp->tiles_per_image, nparts = pp->nparts;
@@ -101,7 +104,7 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
         if (kk * NT + wave * 64 < sl.units) {   // wave-uniform
             int u = kk * NT + tid;
             if (u >= sl.units) u = sl.units - 1;  // tail lanes re-read a valid unit (their LDS slots lie inside the region, unused)
-            const int slot = (int)(((unsigned)u * 43691u) >> 18);  // u / 6 for u < 2^15
+            const int slot = UPR == 6 ? (int)(((unsigned)u * 43691u) >> 18) : u / UPR;  // u / 6 for u < 2^15 (UPR 2: a shift)
             const int pc = u - slot * UPR;
             const int vrow = slot / slots_per_vrow, rem = slot - vrow * slots_per_vrow;
             const int plane = rem >= Wop ? 1 : 0, j = rem - plane * Wop;
@@ -136,7 +139,12 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
     // LDS byte offset of k-group g of chunk c relative to the lane's own pixel slot (row 2*rr, plane 0, j = wo) in half 0.
     // cin = 48: chunks straddle taps (48 = 1.5 chunks), one per-lane value per chunk.  cin = 96: a tap is three whole chunks,
     // offset = tap shift (wave-uniform, computed from constants) + one of three per-lane values.
-    constexpr int NXO = CIN == 48 ? NCH : 3;
+    // k-group g of chunk c covers channels ci .. ci + 7 of tap (32 c + 8 g) / CIN: sub-slot ci / (ROWB / 2), byte (ci % (ROWB / 2)) * 2.
+    //   cin = 48: chunks straddle taps (48 = 1.5 chunks): one per-lane value per chunk;
+    //   cin = 32 / 64 / 96: a tap is 1 / 2 / 3 whole chunks: tap shift (wave-uniform, from constants) + a per-lane value per
+    //   chunk-within-tap.
+    constexpr int CPT = CIN == 48 ? 1 : CIN / 32;                    // chunks per tap (cin = 48: unused)
+    constexpr int NXO = CIN == 48 ? NCH : CPT;
     int xoff[NXO];
     if constexpr (CIN == 48) {
 #pragma unroll
@@ -149,17 +157,17 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
         }
     } else {
 #pragma unroll
-        for (int sub = 0; sub < 3; ++sub) {
+        for (int sub = 0; sub < CPT; ++sub) {
             const int ci = 32 * sub + 8 * g;
-            xoff[sub] = (ci / 48) * HALF_BYTES + (ci % 48) * 2;
+            xoff[sub] = (ci / (ROWB / 2)) * HALF_BYTES + (ci % (ROWB / 2)) * 2;
         }
     }
     auto chunk_off = [&](int c) -> unsigned {   // c is a compile-time constant at every call
         if constexpr (CIN == 48) {
             return (unsigned)xoff[c];
         } else {
-            const int tap = c / 3, dh = tap / 3, dw = tap - 3 * dh;
-            return (unsigned)((dh * slots_per_vrow + (dw & 1) * Wop + (dw >> 1)) * ROWB) + (unsigned)xoff[c % 3];
+            const int tap = c / CPT, dh = tap / 3, dw = tap - 3 * dh;
+            return (unsigned)((dh * slots_per_vrow + (dw & 1) * Wop + (dw >> 1)) * ROWB) + (unsigned)xoff[c % CPT];
         }
     };
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_s2;
@@ -294,8 +302,14 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
     const GLOBAL_AS S2Problem *pp = (const GLOBAL_AS S2Problem *)(probs + prob);
     // <96, 2, 1> (27 chunks x 2 fragments = 216 weight VGPRs) compiles, but needs ~280 registers with everything else and
     // spills 24 of them into scratch -- whose accesses are vector-memory operations in the middle of the counted waits: the
-    // 96-input-channel convolutions stay on the generic kernel (hrnet_mi355.cpp: ConvOp::s2 only for cin == 48)
-    s2_run<48, 3, 2>(pp, ntile, tile0, smem_s2);
+    // 96-input-channel convolutions stay on the generic kernel (hrnet_mi355.cpp: ConvOp::s2 for cin 32 / 48 / 64)
+    const int cin = pp->cin;
+    if (cin == 48)
+        s2_run<48, 3, 2>(pp, ntile, tile0, smem_s2);   // HRNet-W48, branch 0
+    else if (cin == 32)
+        s2_run<32, 2, 2>(pp, ntile, tile0, smem_s2);   // HRNet-W32, branch 0:  9 chunks x 2 fragments =  72 weight VGPRs
+    else
+        s2_run<64, 2, 2>(pp, ntile, tile0, smem_s2);   // HRNet-W32, branch 1: 18 chunks x 2 fragments = 144 weight VGPRs
 }
 
 hipError_t launch_conv_s2(const S2Problem *probs_dev, const void *map_dev, int nblocks, hipStream_t s) {

@@ -305,7 +305,7 @@ struct hrn_ctx {
     // output rows per tile of the stride-2 slab kernel: as many as one slab buffer holds ((2R + 1) virtual input rows of
     // 2 * wop slots of 96 bytes)
     static int s2_rows(int wop, int ho, int cin) {
-        const int vrows = kS2SlabBytes / (2 * wop * cin * 2);
+        const int vrows = s2_slot_capacity(cin) / (2 * wop);
         int r = (vrows - 1) / 2;
         return r > ho ? ho : r;
     }
@@ -353,8 +353,11 @@ struct hrn_ctx {
             op.slices = op.cin / 16, op.ntiles = cout / (16 * op.nr), op.nch = 9;
             op.kpad = 9 * 16 * op.slices;
         }
-        if (dtype == HRN_BF16 && k == 3 && stride == 2 && op.cin == 48 &&   // (cin = 96 does not fit the registers: conv_s2.hip)
-            cout % (16 * s2_frags_per_part(op.cin)) == 0 && !up && !disable_s2 && op.algo == 0 && s2_rows(ow + 1, oh, op.cin) >= 1)
+        if (dtype == HRN_BF16 && k == 3 && stride == 2 && (op.cin == 48 || op.cin == 32 || op.cin == 64) &&   // (cin = 96 does not fit the registers: conv_s2.hip)
+            cout % (16 * s2_frags_per_part(op.cin)) == 0 && !up && !disable_s2 && op.algo == 0 &&
+            // at least two output rows per tile (or the whole image): with one, half of every slab is halo (three input rows
+            // for one output row -- the 64 -> 64 stem conv of a 384x288 net) and the kernel moves 1.5x the tensor
+            (s2_rows(ow + 1, oh, op.cin) >= 2 || s2_rows(ow + 1, oh, op.cin) == oh))
             op.s2 = true;
         convs.push_back(op);
         if (emit) emit_convs({(int)convs.size() - 1});

@@ -68,7 +68,12 @@ hipError_t launch_conv3x3_f32(const Conv3Problem *probs_dev, const void *blockma
 // one fuse level contributes "parts" (48 (32) output channels each) to one problem; a block stages the input slab of `rows`
 // output rows once and its waves keep the parts' weights in registers.
 constexpr int kS2SlabBytes = 79872;   // one slab buffer: 832 sub-slots of 96 bytes (two of them + the biases fill the 160 KiB)
-inline int s2_frags_per_part(int cin) { return cin == 48 ? 3 : 2; }   // 16-cout fragments a wave keeps in registers
+constexpr int s2_frags_per_part(int cin) { return cin == 48 ? 3 : 2; }   // 16-cout fragments a wave keeps in registers
+// a pixel's cin * 2 bytes are kept in LDS as sub-slots of 96 (cin = 48, 96) or 32 (cin = 32, 64) bytes, one region per sub-slot
+// index; a region is a whole number of 1-KiB LDS-DMA pieces
+constexpr int s2_subslot_bytes(int cin) { return cin % 48 == 0 ? 96 : 32; }
+constexpr int s2_region_bytes(int cin) { return kS2SlabBytes / (cin * 2 / s2_subslot_bytes(cin)) / 1024 * 1024; }
+constexpr int s2_slot_capacity(int cin) { return s2_region_bytes(cin) / s2_subslot_bytes(cin); }   // input pixels one slab buffer holds
 constexpr int kS2MaxParts = 8;
 struct S2Part {
     const void *w;      // [K chunks][frags][64 lanes][16 B]: the (cin, frags) image of pack_conv_lds for this cout tile (k = tap * cin + ci)
@@ -79,7 +84,7 @@ struct S2Part {
 };
 struct S2Problem {
     const void *in;     // row 0 of the input tensor
-    int cin;            // 48 or 96
+    int cin;            // 32, 48 or 64
     int in_wp, in_hpwp;
     int ho, wo, wop, out_hpwp;   // output geometry (shared by all parts)
     int rows;                    // output rows per tile

@@ -142,16 +142,19 @@ def test_only_lds_dma_reads_m0_in_the_basicblock_kernel(c3_asm):
 
 
 def test_s2_slab_kernel_register_and_store_invariants(tmp_path):
-    """conv_s2.hip keeps 168 weight registers live and leaves its last stores in flight across the tile barrier with a COUNTED
-    vmcnt (4 = two fragments x two stores): no spills, two waves per SIMD, and exactly that many store instructions."""
+    """conv_s2.hip keeps up to 168 weight registers live and leaves its last stores in flight across the tile barrier with a
+    COUNTED vmcnt (stores per fragment x fragments): no spills, two waves per SIMD, and exactly those store instructions."""
     kernels = _resource_usage("conv_s2.hip", str(tmp_path))
     (name, use), = [(k, v) for k, v in kernels.items() if "conv_s2_slab_kernel" in k]
     assert use["ScratchSize"] == 0 and use.get("VGPRs Spill", 0) == 0 and use["VGPRs"] <= 256 and use["Occupancy"] >= 2, use
     asm = _disassemble("conv_s2.hip", str(tmp_path))
     (ins,) = [v for k, v in asm.items() if "conv_s2_slab_kernel" in k]
     ops = [t.split()[0] for _, t in ins]
-    assert ops.count("global_store_dwordx4") == 2 and ops.count("global_store_dwordx2") == 2, [o for o in ops if "store" in o]
-    assert sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == 14 * 6          # one fully unrolled K loop, nothing duplicated
+    # three instantiations in the kernel -- <48, 3, 2>: per fragment one 16-byte + one 8-byte store; <32, 2, 2> and <64, 2, 2>: one
+    # 16-byte store per fragment; two fragments each: these are the counts the counted waits (vmcnt 4 / 2 / 1) stand on
+    assert ops.count("global_store_dwordx4") == 6 and ops.count("global_store_dwordx2") == 2, [o for o in ops if "store" in o]
+    # one fully unrolled K loop per instantiation, nothing duplicated: 14 x 3 x 2 + 9 x 2 x 2 + 18 x 2 x 2
+    assert sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == 84 + 36 + 72
     # the stores come after every LDS-DMA of the tile loop's flush: the last LDS-DMA before the first store is followed by no other
     first_store = ops.index("global_store_dwordx4")
     assert any(o.startswith("global_load_lds") for o in ops[:first_store])

@@ -25,18 +25,23 @@ def _plan(net, group, n):
     return np.array(blocks[:3 * nb]).reshape(-1, 3), np.array(parts[:5 * npart]).reshape(-1, 5), act.value
 
 
-@pytest.mark.parametrize("c,h,w,mb", [(48, 384, 288, 256), (48, 256, 192, 7), (48, 128, 96, 33), (96, 64, 64, 3)])
+@pytest.mark.parametrize("c,h,w,mb", [(48, 384, 288, 256), (48, 256, 192, 7), (48, 128, 96, 33), (32, 256, 192, 256), (32, 128, 96, 5), (96, 64, 64, 3)])
 def test_s2_block_map_covers_every_tile_once(c, h, w, mb):
     pkg = load_pkg()
     net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=mb, device=-1)
     infos = net.conv_infos()
     s2 = {i for i, ci in enumerate(infos) if ci.algo == 4}
-    if c != 48:
-        assert not s2          # 48 input channels only; every other width stays on the generic kernel
-        return
-    assert len(s2) == 25
     for ci in s2:
-        assert infos[ci].ksize == 3 and infos[ci].stride == 2 and infos[ci].cin == 48
+        assert infos[ci].ksize == 3 and infos[ci].stride == 2 and infos[ci].cin in (32, 48, 64)
+    if c == 96:                # widths 96 / 192 / 384 / 768: only the 64 -> 64 stem conv has a supported input width
+        assert {infos[i].name.decode() for i in s2} <= {"conv2"}
+        if not s2:
+            net.close()
+            return
+    else:
+        fuse = {i for i in s2 if b"fuse_layers" in infos[i].name}
+        assert len(fuse) == (25 if c == 48 else 25 + 10)       # W48: branch 0 (cin 48); W32: branches 0 and 1 (cin 32, 64)
+        assert s2 - fuse <= {i for i, ci in enumerate(infos) if ci.name in (b"conv2", b"transition2.2.0.0")}
     seen_parts = set()
     g = 0
     while True:
@@ -49,7 +54,8 @@ def test_s2_block_map_covers_every_tile_once(c, h, w, mb):
             for prob, conv, tile48, rows, tpi in parts:
                 ci = infos[conv]
                 wop = ci.out_w + 1
-                assert (2 * rows + 1) * 2 * wop * 96 <= 79872 and 1 <= rows <= ci.out_h
+                cap = {32: 1248, 48: 832, 64: 608}[ci.cin]           # input pixels one slab buffer holds (kernels.h: s2_slot_capacity)
+                assert (2 * rows + 1) * 2 * wop <= cap and 1 <= rows <= ci.out_h
                 assert tpi == -(-ci.out_h // rows)
                 tiles[prob] = n * tpi
                 if n == mb:
@@ -67,19 +73,19 @@ def test_s2_block_map_covers_every_tile_once(c, h, w, mb):
             g += 1
             continue
         break
-    assert g >= 15
-    # every 48-cout tile of every member convolution is somebody's part
-    assert seen_parts == {(ci, t) for ci in s2 for t in range(infos[ci].cout // 48)}
+    assert g >= 1
+    # every cout tile (48 couts for cin = 48, 32 otherwise) of every member convolution is somebody's part
+    assert seen_parts == {(ci, t) for ci in s2 for t in range(infos[ci].cout // (48 if infos[ci].cin == 48 else 32))}
     net.close()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("h,w,n", [(384, 288, 3), (256, 192, 5), (128, 96, 4), (64, 64, 2), (320, 224, 2), (512, 384, 2), (96, 160, 3), (32, 32, 7)])
-def test_s2_kernel_on_off_is_bit_identical(monkeypatch, h, w, n):
+@pytest.mark.parametrize("c,h,w,n", [(48, 384, 288, 3), (48, 256, 192, 5), (48, 128, 96, 4), (48, 64, 64, 2), (48, 320, 224, 2), (48, 512, 384, 2), (48, 96, 160, 3),
+                                     (48, 32, 32, 7), (32, 256, 192, 5), (32, 384, 288, 2), (32, 128, 96, 4), (32, 64, 64, 3), (64, 128, 96, 2)])
+def test_s2_kernel_on_off_is_bit_identical(monkeypatch, c, h, w, n):
     """HRN_S2_MIN_TILES=1 forces the slab kernel at any batch size; HRN_DISABLE_S2 routes the same convolutions to the
     generic kernel.  Same K order, same MFMA operand layout, bias added last in both: identical bits."""
     pkg = load_pkg()
-    c = 48
     x = torch.from_numpy(pkg.synth_crops(n, h, w, seed=31)).cuda()
     out = {}
     for tag in ("on", "off"):
@@ -88,7 +94,7 @@ def test_s2_kernel_on_off_is_bit_identical(monkeypatch, h, w, n):
         if tag == "off":
             monkeypatch.setenv("HRN_DISABLE_S2", "1")
         net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=n, device=0).load_state_dict(state_dict_np(c))
-        assert sum(i.algo == 4 for i in net.conv_infos()) == (25 if tag == "on" else 0)
+        assert (sum(i.algo == 4 for i in net.conv_infos()) >= 25) == (tag == "on")
         out[tag] = net(x).cpu().numpy()
         # the member convolutions themselves, before anything downstream could hide a difference
         taps = [t.name.decode() for t in net.tap_infos() if ".fuse_layers." in t.name.decode()]
