@@ -20,7 +20,7 @@ if os.environ.get("HRN_LIB_TAG"):   # A/B runs of compile-time variants (tools/m
     LIB_PATH = LIB_PATH.replace(".so", "_%s.so" % os.environ["HRN_LIB_TAG"])
 SOURCES = ["kernels.hip", "conv3x3_lds.hip", "conv_s2.hip", "conv3x3_f32.hip", "bottleneck_chain.hip", "prepath.hip", "nms.hip", "postproc.cpp", "hrnet_mi355.cpp"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv3x3_n96.inc"), os.path.join(INCLUDE, "hrnet_mi355.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-Wno-inline-asm"]
 
 
 def _hipcc() -> str:
@@ -30,33 +30,74 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the MI355X HRNet library cannot be built")
 
 
+def _obj_dir() -> str:
+    """objects live beside the library they are linked into (a tagged variant -- other -D flags -- has its own)"""
+    return LIB_PATH[:-3] + "_obj"
+
+
+def _deps(src: str) -> List[str]:
+    """files whose change invalidates the object of `src` (every source includes kernels.h; conv3x3_lds.hip the .inc files)"""
+    d = [os.path.join(CSRC, src)] + HEADERS
+    return d + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".inc") or f.endswith(".h")]
+
+
+def _obj(src: str) -> str:
+    return os.path.join(_obj_dir(), src.rsplit(".", 1)[0] + ".o")
+
+
+def _stale(src: str) -> bool:
+    o = _obj(src)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(d) > t for d in _deps(src))
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     if os.environ.get("HRN_LIB_TAG"):
         return False                  # a tagged variant is used as built
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    deps = set()
+    for s in SOURCES:
+        deps.update(_deps(s))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source of the package for gfx950 into ``libhrnet_mi355.so``.
+    """Compile every HIP source of the package for gfx950 into ``libhrnet_mi355.so``: one object per source (only the
+    stale ones, in parallel), then one link.
 
     Safe under concurrent callers (the N ranks of a torch.distributed launch all import the package): the build
-    runs under an exclusive file lock, into a per-process temporary, and is skipped by whoever arrives second."""
+    runs under an exclusive file lock, into per-process temporaries, and is skipped by whoever arrives second."""
     if not force and not needs_build():
         return LIB_PATH
     import fcntl
+    from concurrent.futures import ThreadPoolExecutor
 
     with open(LIB_PATH + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if force or needs_build():
+                os.makedirs(_obj_dir(), exist_ok=True)
+                cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+
+                def compile_one(src):
+                    tmp = "%s.tmp.%d" % (_obj(src), os.getpid())
+                    cmd = [_hipcc()] + cflags + ["-c", "-o", tmp, os.path.join(CSRC, src)]
+                    if verbose:
+                        print(" ".join(cmd), flush=True)
+                    subprocess.check_call(cmd)
+                    os.replace(tmp, _obj(src))
+
+                todo = [s for s in SOURCES if force or _stale(s)]
+                with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4) or 1) as ex:
+                    list(ex.map(compile_one, todo))
                 tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
-                cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+                cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [_obj(s) for s in SOURCES]
                 if verbose:
-                    print(" ".join(cmd))
+                    print(" ".join(cmd), flush=True)
                 subprocess.check_call(cmd)
                 os.replace(tmp, LIB_PATH)
         finally:

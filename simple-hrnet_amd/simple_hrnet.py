@@ -33,15 +33,33 @@ _MEAN = (0.485, 0.456, 0.406)   # SimpleHRNet.py:171
 _STD = (0.229, 0.224, 0.225)
 
 
+# (local-rank variable, task-count variables of the same launcher): srun / mpirun export their local rank even for a one-task
+# job, so the variable only means "one GPU per process" when the job has more than one task
+_LAUNCHERS = (("SLURM_LOCALID", ("SLURM_NTASKS", "SLURM_NPROCS")),
+              ("OMPI_COMM_WORLD_LOCAL_RANK", ("OMPI_COMM_WORLD_SIZE",)),
+              ("MV2_COMM_WORLD_LOCAL_RANK", ("MV2_COMM_WORLD_SIZE",)),
+              ("MPI_LOCALRANKID", ("PMI_SIZE",)))
+
+
 def _launcher_local_rank() -> Optional[int]:
-    """the local rank a multi-process launcher gave this process, or None for a plain process.  ``torch.distributed.run`` sets
-    LOCAL_RANK; srun / mpirun set their own variables and no LOCAL_RANK -- under any of them a process drives ONE GPU (a
-    rank that built an engine on every visible GPU would oversubscribe the node)."""
-    for key in ("LOCAL_RANK", "SLURM_LOCALID", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID"):
+    """the GPU slot a multi-process launcher gave this process, or None for a plain process.  ``torch.distributed.run`` sets
+    LOCAL_RANK (taken as it is: torchrun does not restrict the visible devices).  srun / mpirun set their own variables and
+    no LOCAL_RANK -- under any of them a process drives ONE GPU (a rank that built an engine on every visible GPU would
+    oversubscribe the node) -- but only when the job really has several tasks, and the rank is folded onto the
+    devices this task can SEE: under ``srun --gpus-per-task=1`` / gpu-bind every task sees a single GPU at index 0 while
+    SLURM_LOCALID runs 0..7."""
+    if "LOCAL_RANK" in os.environ:
+        return int(os.environ["LOCAL_RANK"])
+    ndev = max(1, torch.cuda.device_count())
+    for key, sizes in _LAUNCHERS:
         if key in os.environ:
-            return int(os.environ[key])
+            ntasks = max([int(os.environ[k]) for k in sizes if os.environ.get(k, "").isdigit()] or [0])
+            if ntasks == 0 and os.environ.get("WORLD_SIZE", "").isdigit():
+                ntasks = int(os.environ["WORLD_SIZE"])
+            if ntasks > 1:
+                return int(os.environ[key]) % ndev
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ:   # a launcher without a local-rank variable
-        return int(os.environ["RANK"]) % max(1, torch.cuda.device_count())
+        return int(os.environ["RANK"]) % ndev
     return None
 
 

@@ -12,12 +12,17 @@ from conftest import load_pkg, state_dict_np
 
 
 # --------------------------------------------------------------------------------------------- device mapping (CPU)
-@pytest.mark.parametrize("env", [{"LOCAL_RANK": "1"}, {"SLURM_LOCALID": "1", "SLURM_PROCID": "5"}, {"OMPI_COMM_WORLD_LOCAL_RANK": "1"}])
+_LAUNCH_VARS = ("LOCAL_RANK", "SLURM_LOCALID", "SLURM_NTASKS", "SLURM_NPROCS", "OMPI_COMM_WORLD_LOCAL_RANK", "OMPI_COMM_WORLD_SIZE",
+                "MV2_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_SIZE", "MPI_LOCALRANKID", "PMI_SIZE", "RANK", "WORLD_SIZE")
+
+
+@pytest.mark.parametrize("env", [{"LOCAL_RANK": "1"}, {"SLURM_LOCALID": "1", "SLURM_PROCID": "5", "SLURM_NTASKS": "8"},
+                                 {"OMPI_COMM_WORLD_LOCAL_RANK": "1", "OMPI_COMM_WORLD_SIZE": "2"}])
 def test_launchers_other_than_torchrun_get_one_gpu_per_process(monkeypatch, env):
     """srun / mpirun set their own local-rank variables and no LOCAL_RANK: a rank given device='cuda' must take ITS GPU, not
     build an engine on every visible one."""
     sh = load_pkg("simple_hrnet")
-    for k in ("LOCAL_RANK", "SLURM_LOCALID", "OMPI_COMM_WORLD_LOCAL_RANK", "RANK", "WORLD_SIZE"):
+    for k in _LAUNCH_VARS:
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
     assert sh.resolve_devices("cuda") == list(range(8))            # a plain process: DataParallel over all of them
@@ -28,9 +33,28 @@ def test_launchers_other_than_torchrun_get_one_gpu_per_process(monkeypatch, env)
     assert sh.resolve_devices(torch.device("cuda")) == [1]
 
 
+def test_srun_with_one_gpu_per_task_and_single_task_jobs(monkeypatch):
+    """under `srun --gpus-per-task=1` every task sees ONE GPU at index 0 while SLURM_LOCALID runs 0..7 -- the
+    local rank is folded onto the visible devices; and a one-task `srun python ...` is a plain process (all visible GPUs)."""
+    sh = load_pkg("simple_hrnet")
+    for k in _LAUNCH_VARS:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setenv("SLURM_LOCALID", "3")
+    monkeypatch.setenv("SLURM_NTASKS", "8")
+    assert sh.resolve_devices("cuda") == [0] and sh.resolve_device("cuda").index == 0 and sh.resolve_device(None).index == 0
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert sh.resolve_devices("cuda") == [3]
+    monkeypatch.setenv("SLURM_NTASKS", "1")                         # single task: not launcher-managed
+    monkeypatch.setenv("SLURM_LOCALID", "0")
+    assert sh.resolve_devices("cuda") == list(range(8))
+    monkeypatch.delenv("SLURM_NTASKS")                              # no task count at all: not enough to claim a launcher
+    assert sh.resolve_devices("cuda") == list(range(8))
+
+
 def test_rank_and_world_size_without_a_local_rank(monkeypatch):
     sh = load_pkg("simple_hrnet")
-    for k in ("LOCAL_RANK", "SLURM_LOCALID", "OMPI_COMM_WORLD_LOCAL_RANK"):
+    for k in _LAUNCH_VARS:
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
     monkeypatch.setenv("RANK", "6")
@@ -42,7 +66,7 @@ def test_rank_and_world_size_without_a_local_rank(monkeypatch):
 
 def test_torch_device_without_a_visible_gpu_names_gpu_zero(monkeypatch):
     sh = load_pkg("simple_hrnet")
-    for k in ("LOCAL_RANK", "SLURM_LOCALID", "OMPI_COMM_WORLD_LOCAL_RANK", "RANK", "WORLD_SIZE"):
+    for k in _LAUNCH_VARS:
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
     assert sh.resolve_devices(torch.device("cuda")) == [0] and sh.resolve_devices("cuda") == [0]   # (creating the engine then says there is no such device)
