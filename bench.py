@@ -18,7 +18,10 @@ Prints ONE JSON line on rank 0: the driver-contract fields plus
                 bf16 engine: arg-max agreement and pixel histogram)
   cpu_baseline  N=1: the reference's device='cpu' path restated (oracle), max_batch_size=32 chunks, on this box's cores
   clip          N=1: BASELINE configs[4] -- 30 synthetic 1080p frames x 8 detector boxes, frame -> crops -> joints
+  parity.peaked N=1: the timed configuration on the PEAKED checkpoint (synth.peaked_state_dict) against the fp32 CPU oracle and
+                against the cell the construction puts every joint's peak in
   config1_fp32  N=1: BASELINE configs[1] -- HRNet-W32 256x192, batch 64, fp32, against the fp32 MFMA peak
+  fp32_w48_384x288  N=1: the headline shape in the parity mode (fp32), timed
   prepath, pcie_inclusive   side measurements
 """
 from __future__ import annotations
@@ -63,6 +66,8 @@ def parse():
     ap.add_argument("--no-prepath", action="store_true", help="skip the crop pre-path / PCIe side measurements")
     ap.add_argument("--no-clip", action="store_true", help="skip the configs[4] clip block")
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] fp32 side line")
+    ap.add_argument("--no-peaked", action="store_true", help="skip parity.peaked (bf16 px-match on the peaked checkpoint)")
+    ap.add_argument("--no-fp32-w48", action="store_true", help="skip the fp32 line on the headline shape")
     ap.add_argument("--clip", action="store_true", help="ONLY the configs[4] clip measurement (its JSON line is the clip block)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -138,6 +143,14 @@ def _cpu_worker(spec_path):
             break
     if spec.get("out"):
         extra = {}
+        pk = spec.get("peaked")
+        if pk:
+            # the peaked checkpoint (synth.peaked_state_dict: random trunk + three signal channels on the identity paths) on a few
+            # crops spread through the batch the GPU runs, on-cell and off-cell blob centres; outside the timed sample
+            psd = pkg.synth.to_torch_state_dict(pkg.synth.peaked_state_dict(c, 17, 0))
+            for tag, on_cell in (("on", True), ("off", False)):
+                pc, _ = pkg.synth.peaked_crops(pk["n"], h, w, seed=pk["seed"], on_cell=on_cell)
+                extra["peaked_%s_hm" % tag] = T.hrnet_forward(psd, torch.from_numpy(pc[pk["idx"]])).numpy()
         if spec.get("emulate_bf16"):
             # the engine-arithmetic restatement (bf16 weights and stored activations, fp32 accumulation) of the same crops:
             # what the bf16 kernels are pinned to; outside the timed sample
@@ -458,6 +471,97 @@ def config1_measure(pkg, dev):
                          "timing": "HIP events on the launch stream around every kernel of one pass of 64 crops"}}
 
 
+PEAKED_IDX = [0, 37, 74, 111, 148, 185, 222, 255]   # crops of the 256-crop peaked batch the CPU oracle also evaluates
+PEAKED_SEED = 5
+
+
+def peaked_measure(pkg, a, dev, cpu_out):
+    """bf16 px-match on heat-maps that HAVE a peak: the engine in the timed configuration (same dtype, batch,
+    micro-batch) on the peaked checkpoint / crops of synth.py, against (i) the fp32 CPU oracle on PEAKED_IDX and (ii) the cell the
+    construction puts the peak in, for every (crop, joint) of the batch."""
+    import numpy as np
+    import torch
+
+    ref = np.load(cpu_out)
+    n, h4, w4 = a.batch, a.height // 4, a.width // 4
+    idx = [i for i in PEAKED_IDX if i < n]
+    net = pkg.NativeHRNet(a.c, 17, (a.height, a.width), a.dtype, max_batch=a.max_batch, device=dev.index)
+    sdp = pkg.synth.peaked_state_dict(a.c, 17, 0)
+    net.load_state_dict(sdp)
+    mix = sdp["final_layer.weight"][:, :pkg.synth.PEAKED_SIGNALS, 0, 0]
+    boxes = torch.from_numpy(np.tile(np.asarray([[0, 0, a.width, a.height]], np.int32), (n, 1))).to(dev)   # box = the crop: pts in crop px
+    out = {"weights": "synth.peaked_state_dict(c, 17, 0): the seeded random checkpoint with three signal channels on the identity paths "
+                      "(leak 0.05 from the random channels at every layer), head = signal mix + 0.25 x random",
+           "crops": "synth.peaked_crops(%d, %d, %d, seed %d): one blob (sigma 6 px, amplitude 20-30) per colour plane on N(0, 0.2) noise" % (n, a.height, a.width, PEAKED_SEED),
+           "reference": "fp32 CPU oracle on crops %s of the batch; construction (strongest weighted blob's cell) on all %d x 17 joints" % (idx, n),
+           "px_unit": "crop pixels (one heat-map cell = 4 px; the reference decodes without sub-cell refinement, SimpleHRNet.py:297-308)"}
+    for tag, on_cell in (("on", True), ("off", False)):
+        key = "peaked_%s_hm" % tag
+        if key not in ref.files:
+            continue
+        crops, cen = pkg.synth.peaked_crops(n, a.height, a.width, seed=PEAKED_SEED, on_cell=on_cell)
+        hm, pts = net.predict_crops(torch.from_numpy(crops).to(dev), boxes, return_heatmaps=True)
+        hm, pts = hm.cpu().numpy(), pts.cpu().numpy()
+        ref_hm = ref[key]
+        k = len(idx)
+        flat, rflat = hm[idx].reshape(k, 17, -1), ref_hm.reshape(k, 17, -1)
+        am, ram = flat.argmax(-1), rflat.argmax(-1)
+        cells = np.maximum(np.abs(am // w4 - ram // w4), np.abs(am % w4 - ram % w4))
+        srt = np.sort(rflat, -1)
+        margin = srt[..., -1] - srt[..., -2]
+        err = float(np.abs(hm[idx] - ref_hm).max())
+        safe = margin > 4 * err
+        # construction: joint j peaks on the blob s maximising mix[j, s] * amplitude -- take the blob nearest to the engine's peak
+        amall = hm.reshape(n, 17, -1).argmax(-1)
+        py, px = amall // w4, amall % w4
+        d = np.min(np.maximum(np.abs(py[:, :, None] - cen[:, None, :, 0] / 4.0), np.abs(px[:, :, None] - cen[:, None, :, 1] / 4.0)), -1)
+        res = {"argmax_agree_frac": round(float((am == ram).mean()), 4), "joints_compared": int(am.size),
+               "max_dev_px": int(cells.max() * 4), "px_hist": {"0": int((cells == 0).sum()), "4": int((cells == 1).sum()), ">4": int((cells > 1).sum())},
+               "max_abs_dH": round(err, 4), "peak_median": round(float(np.median(srt[..., -1])), 3),
+               "margin_min": round(float(margin.min()), 4), "margin_median": round(float(np.median(margin)), 4),
+               "frac_margin_gt_4err": round(float(safe.mean()), 4),
+               "agree_where_margin_gt_4err": (round(float((am == ram)[safe].mean()), 4) if safe.any() else None),
+               "all_joints_max_cells_from_a_blob_centre": round(float(d.max()), 3),
+               "all_joints_on_a_blob_cell_frac": round(float((d <= (0.0 if on_cell else 0.75)).mean()), 4)}
+        out["on_cell" if on_cell else "off_cell"] = res
+    net.close()
+    return out
+
+
+def fp32_w48_measure(pkg, a, dev):
+    """The configuration in which +-0.5 px holds today -- fp32 (exact-fp32 MFMA) on the HEADLINE shape: HRNet-W48 384x288, batch
+    256 -- timed like the headline."""
+    import torch
+
+    c, h, w, n = 48, 384, 288, 256
+    net = pkg.NativeHRNet(c, 17, (h, w), "fp32", max_batch=n, device=dev.index).load_state_dict(pkg.synth_state_dict(c, 17, 0))
+    g = torch.Generator(device=dev).manual_seed(1234)
+    images = torch.randn((n, 3, h, w), generator=g, device=dev, dtype=torch.float32)
+    boxes = torch.from_numpy(pkg.synth_boxes(n, seed=100)).to(dev)
+    net.predict_crops(images, boxes)
+    torch.cuda.synchronize()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        net.predict_crops(images, boxes)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    value = steps * n / el
+    flops = net.flops_per_crop()
+    conv_ms, other = net.profile_pass(images)
+    conv_ms, other = net.profile_pass(images)
+    infos = net.conv_infos()
+    conv_tf = sum(i.flops for i in infos) * n / (sum(conv_ms) * 1e-3) / 1e12
+    net.close()
+    return {"workload": "HRNet-W48 384x288, batch=256 random crops, fp32 (v_mfma_f32_16x16x4_f32), model forward + decode: the headline "
+                        "shape in the parity mode (joint coordinates identical to the CPU reference, parity.fp32_coords_identical)",
+            "value": round(value, 1), "unit": "crops/s", "ms_per_step": round(el / steps * 1e3, 3), "dtype": "f32", "steps": steps,
+            "whole_net_tflops": round(value * flops / 1e12, 2),
+            "roofline": {"bound": "mfma", "kernel": "all convolutions of the pass (HIP events around every kernel of one pass)",
+                         "achieved": round(conv_tf, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tf / PEAK_F32_TFLOPS, 4),
+                         "whole_net_frac": round(value * flops / 1e12 / PEAK_F32_TFLOPS, 4)}}
+
+
 def parity_measure(pkg, net, a, images, boxes, dev, cpu_out):
     """The first PARITY_CROPS crops of the timed batch, taken from a full-batch call (the batch-256 code path itself),
     against the CPU oracle's outputs for the same crops (computed by the cpu_baseline worker)."""
@@ -704,7 +808,8 @@ def main():
             k = min(PARITY_CROPS, a.batch)
             spec = {"c": a.c, "h": a.height, "w": a.width, "budget_s": a.cpu_seconds, "crops": os.path.join(tmpdir, "crops.npy"),
                     "boxes": boxes_np[:k].tolist(), "out": os.path.join(tmpdir, "ref.npz"), "clip": None,
-                    "emulate_bf16": a.dtype == "bf16" and a.model_name == "HRNet"}
+                    "emulate_bf16": a.dtype == "bf16" and a.model_name == "HRNet",
+                    "peaked": None if a.no_peaked else {"n": a.batch, "seed": PEAKED_SEED, "idx": [i for i in PEAKED_IDX if i < a.batch]}}
             np.save(spec["crops"], images[:k].cpu().numpy())
             if not a.no_clip:
                 clip, dets = make_clip()
@@ -717,6 +822,11 @@ def main():
                     out["parity"] = parity_measure(pkg, net, a, images, boxes, dev, spec["out"])
                 except Exception as e:   # never lose the GPU number to the checker
                     out["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                if not a.no_peaked:
+                    try:
+                        out["parity"]["peaked"] = peaked_measure(pkg, a, dev, spec["out"])
+                    except Exception as e:
+                        out["parity"]["peaked"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not a.no_clip and a.model_name == "HRNet":
             try:
                 res, (clip, dets, gpu_pts) = clip_measure(pkg, net, None, 0, 1, (cpu or {}).get("clip"))
@@ -735,6 +845,11 @@ def main():
                 out["config1_fp32"] = config1_measure(pkg, dev)
             except Exception as e:
                 out["config1_fp32"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not a.no_fp32_w48 and a.model_name == "HRNet":
+            try:
+                out["fp32_w48_384x288"] = fp32_w48_measure(pkg, a, dev)
+            except Exception as e:
+                out["fp32_w48_384x288"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not a.no_prepath:
             out["prepath"] = prepath_measure(pkg, net, dev)
             out["pcie_inclusive"] = pcie_measure(pkg, net, min(a.batch, a.max_batch), dev)

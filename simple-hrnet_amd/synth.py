@@ -190,3 +190,105 @@ def to_torch_state_dict(sd: Dict[str, np.ndarray]):
     import torch
 
     return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in sd.items())
+
+
+# ----------------------------------------------------------------------------------------------- peaked checkpoint
+# A random-init HRNet produces near-flat heat-maps (median top-1 / top-2 gap 1.7e-2 at sigma 5.7): their
+# arg-max is decided by the last bits, so "same joint coordinates" cannot be asserted for the bf16 engine on them.  A
+# trained network has ONE dominant blob per joint.  No trained weights exist offline, and a linear read-out of the random
+# trunk's final features cannot localise anything (tried: least squares of a Gaussian target on the branch-0 features of
+# 16 marked crops peaks at the marker for 1.5 % of the joints -- a deep random trunk scrambles position), so the peaked
+# checkpoint is BUILT: the random checkpoint above with three "signal" channels laid through the identity paths of the
+# graph (stem -> layer1's shortcut -> transition1.0 -> the residual connections of branch 0 -> the i == j terms of the
+# fuse sums, hrnet.py:60-69), every weight that writes into those channels from elsewhere scaled by `leak` (NOT zeroed:
+# the channels pick up the random network's activity and its bf16 rounding noise at every one of the ~40 stored tensors
+# on the way), and a final layer that reads each joint from a mix of the three signals plus the usual random weights on
+# the other channels.  Crops for it carry one positive blob per colour plane on weak noise; joint j then peaks where the
+# strongest weighted blob sits, with a margin to the neighbouring cell of ~12 % of the peak (sigma = 2 cells).
+PEAKED_SIGNALS = 3
+
+
+def peaked_state_dict(c: int = 48, nof_joints: int = 17, seed: int = 0, leak: float = 0.05,
+                      head_noise: float = 0.25) -> "OrderedDict[str, np.ndarray]":
+    """The seeded random checkpoint with three signal channels (see above).  Pure numpy, reference independent."""
+    sd = synth_state_dict(c, nof_joints, seed)
+    S = PEAKED_SIGNALS
+
+    def ident_bn(prefix, ch=S):          # y = x (up to the eps in the denominator)
+        sd[prefix + ".weight"][:ch] = 1.0
+        sd[prefix + ".bias"][:ch] = 0.0
+        sd[prefix + ".running_mean"][:ch] = 0.0
+        sd[prefix + ".running_var"][:ch] = 1.0
+
+    def leak_into(conv, bn, ch=S):       # out channels 0..ch-1 of (conv, bn): only a leak of the random activity
+        sd[conv + ".weight"][:ch] *= leak
+        sd[bn + ".bias"][:ch] *= leak
+        sd[bn + ".running_mean"][:ch] *= leak
+
+    # stem: a 3x3 mean of colour plane s, twice (stride 2 each) -> 1/4 resolution
+    for conv, bn, cin in (("conv1", "bn1", 3), ("conv2", "bn2", 64)):
+        w = sd[conv + ".weight"]
+        w[:S] *= leak
+        for s in range(S):
+            w[s, s] += 1.0 / 9.0
+        ident_bn(bn)
+    # layer1: the projection shortcut of block 0 carries the signals, the other blocks' identity shortcuts keep them
+    w = sd["layer1.0.downsample.0.weight"]
+    w[:S] *= leak
+    for s in range(S):
+        w[s, s, 0, 0] += 1.0
+    ident_bn("layer1.0.downsample.1")
+    for b in range(4):
+        leak_into("layer1.%d.conv3" % b, "layer1.%d.bn3" % b)
+    # transition1.0: centre tap
+    w = sd["transition1.0.0.weight"]
+    w[:S] *= leak
+    for s in range(S):
+        w[s, s, 1, 1] += 1.0
+    ident_bn("transition1.0.1")
+    # branch 0 of every stage module: the residual connection carries the signals; fuse terms into output 0 only leak
+    for name, nbranch in (("stage2.0", 2), ("stage3.0", 3), ("stage3.1", 3), ("stage3.2", 3), ("stage3.3", 3),
+                          ("stage4.0", 4), ("stage4.1", 4), ("stage4.2", 4)):
+        for k in range(4):
+            leak_into("%s.branches.0.%d.conv2" % (name, k), "%s.branches.0.%d.bn2" % (name, k))
+        for j in range(1, nbranch):
+            leak_into("%s.fuse_layers.0.%d.0" % (name, j), "%s.fuse_layers.0.%d.1" % (name, j))
+    # head: joint j reads signal j % 3 with weight 1 and the others with U(0, 0.4); the random weights on the other
+    # channels stay, scaled so that their field (sigma ~ 1.6 unscaled) cannot reach the blobs' height
+    g = _rng_for(seed, "peaked.head")
+    w = sd["final_layer.weight"]
+    w *= head_noise
+    mix = g.uniform(0.0, 0.4, size=(nof_joints, S)).astype(np.float32)
+    for j in range(nof_joints):
+        mix[j, j % S] = 1.0
+    w[:, :S, 0, 0] = mix
+    sd["final_layer.bias"] *= head_noise
+    return sd
+
+
+def peaked_crops(n: int, height: int, width: int, seed: int = 5, sigma_px: float = 6.0, noise: float = 0.2, on_cell: bool = True):
+    """(n,3,H,W) fp32 crops for `peaked_state_dict`: per colour plane ONE positive Gaussian blob (sigma 6 input pixels = 1.5
+    heat-map cells, amplitude U(20, 30), centre seeded, at least 16 px from the border and from the other planes' blobs)
+    on N(0, 0.2) noise.  ``on_cell``: centres are multiples of 4 -- the input pixel heat-map cell (Y, X) is centred on
+    (two 3x3 / stride-2 / pad-1 convolutions: 4Y, 4X) -- so the peak cell beats its neighbours by ~20 % of its height;
+    off-cell centres can sit between two cells, whose values then tie to within the bf16 noise whatever the network
+    (the reference decodes without sub-cell refinement, SimpleHRNet.py:297-308: one cell = 4 px of the crop).
+    Returns (crops, centres (n,3,2) int: y, x in input pixels)."""
+    g = np.random.default_rng([seed, n, height, width])
+    x = (noise * g.standard_normal((n, 3, height, width))).astype(np.float32)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float32)
+    centres = np.zeros((n, PEAKED_SIGNALS, 2), np.int64)
+    for i in range(n):
+        chosen = []
+        for s in range(PEAKED_SIGNALS):
+            for _ in range(1000):
+                cy, cx = int(g.integers(16, height - 16)), int(g.integers(16, width - 16))
+                if on_cell:
+                    cy, cx = cy // 4 * 4, cx // 4 * 4
+                if all(max(abs(cy - a), abs(cx - b)) >= 16 for a, b in chosen):
+                    break
+            chosen.append((cy, cx))
+            amp = float(g.uniform(20.0, 30.0))
+            x[i, s] += amp * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2.0 * sigma_px * sigma_px))
+        centres[i] = chosen
+    return x, centres

@@ -52,7 +52,7 @@ def test_batch256_w48_384x288_path_meets_the_oracle(pkg):
     sigma = ref_hm.std()
     for dtype in ("bf16", "fp32"):
         net = pkg.NativeHRNet(c, 17, (h, w), dtype, max_batch=256, device=0).load_state_dict(state_dict_np(c))
-        assert sum(i.algo == 2 for i in net.conv_infos()) == (64 if dtype == "bf16" else 0)   # the fused pass is in play
+        assert (sum(i.algo == 2 for i in net.conv_infos()) > 0) == (dtype == "bf16")   # the fused pass is in play
         hm, pts = net.predict_crops(crops, boxes, return_heatmaps=True)
         hm, pts = hm[pick].cpu().numpy(), pts[pick].cpu().numpy()
         err = np.abs(hm - ref_hm).max()
