@@ -222,6 +222,13 @@ int hrn_launches_per_pass(hrn_handle h);
  * the block's conv2).  Returns the number of blocks (may exceed capacity), -1 for a bad group / n. */
 int hrn_plan_block_map(hrn_handle h, int group, int n, int reverse, int32_t *blocks, int capacity, int32_t *members,
                        int member_capacity);
+/* The persistent work-queue form (round 4) of the `group`-th grouped BasicBlock launch for a call of n crops: one block per CU
+ * draws units -- (convolution, 96-cout tile, run of 512-pixel M tiles) -- from per-XCD lists; per unit four int32
+ * (convolution index, cout tile, first M tile, M tiles), in queue order.  info[0..3] = the convolution whose fused
+ * BasicBlock is dealt out in equal tile ranges instead of queued (-1: none), the number of blocks that take a range, its
+ * 512-pixel tiles, the number of blocks of the launch.  Returns the number of units (may exceed capacity), -1 for a bad
+ * group / n, -2 when the launch takes the per-block form (hrn_plan_block_map) at this n.  Works on plan-only handles. */
+int hrn_plan_queue(hrn_handle h, int group, int n, int reverse, int32_t *units, int capacity, int32_t *info);
 /* Likewise for the `group`-th grouped launch of the generic kernel: per block three int32 (descriptor, cout tile, M tile;
  * M tiles past the end are alignment padding and return at once), members[d] = convolution index, *pixels_per_tile =
  * 64 * (fragments per wave chosen for n). */

@@ -161,6 +161,7 @@ SYMBOLS = {
     "hrn_map_rebuilds": (ctypes.c_int64, [_P]),
     "hrn_launches_per_pass": (ctypes.c_int, [_P]),
     "hrn_plan_block_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int]),
+    "hrn_plan_queue": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P]),
     "hrn_plan_direct_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, _P]),
     "hrn_plan_s2_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, _P]),
     "hrn_profile_pass": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_int,

@@ -820,12 +820,27 @@ __device__ __forceinline__ void bbf_run(const Conv3Problem &p, const int mt0, co
 }
 
 #include "conv3x3_n96.inc"
+#include "conv3x3_queue.inc"
 
 template <int KS, int NRB>
 __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem *__restrict__ probs,
                                                              const int2 *__restrict__ blockmap, const int nb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using CFG = C3Cfg<KS, NRB>;
+#ifdef HRN_Q_TIMING   // debug (tools/c3q_test.hip): which CU ran this block, from when to when (s_memrealtime, 100 MHz)
+    struct Stamp {
+        long long t0;
+        __device__ Stamp() : t0((long long)__builtin_amdgcn_s_memrealtime()) {}
+        __device__ ~Stamp() {
+            if (g_q_timing && threadIdx.x == 0) {
+                unsigned hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+                g_q_timing[blockIdx.x * 4 + 0] = t0, g_q_timing[blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+                g_q_timing[blockIdx.x * 4 + 3] = (long long)(((xcc & 15u) << 16) | (hw & 0xff00u));   // XCC, SE / SH / CU bits of HW_ID
+            }
+        }
+    } stamp_;
+#endif
     const int2 bm = blockmap[blockIdx.x];
     // block map entry: x = problem | cout tile << 8 | M tiles of this block << 16,  y = first M tile
     const Conv3Problem p = probs[bm.x & 0xff];
@@ -891,6 +906,11 @@ static hipError_t launch_c3(const Conv3Problem *probs_dev, const int2 *blockmap_
     }
     hipLaunchKernelGGL((conv3x3_lds_kernel<KS, NRB>), dim3(nblocks), dim3(512), LDS, s, probs_dev, blockmap_dev, nb);
     return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_queue(const QUnit *qunits_dev, int nunits, int *heads_dev, const Conv3Problem *probs_dev, int bbf_prob,
+                                int bbf_blocks, int bbf_tiles, int rev, int nb, int nblocks, hipStream_t s) {
+    return launch_c3_queue(qunits_dev, nunits, heads_dev, probs_dev, bbf_prob, bbf_blocks, bbf_tiles, rev, nb, nblocks, s);
 }
 
 int conv3x3_n96_ch64() { return N96_CH64; }

@@ -70,6 +70,10 @@ struct MapSlot {
     int mr = 4;                  // generic kernel: 16-pixel fragments per wave of this map
     int2 *dev = nullptr, *pin = nullptr;
     ConvArgs *args_dev = nullptr, *args_pin = nullptr;  // generic kernel only
+    // persistent work-queue form of a grouped BasicBlock launch (conv3x3_queue.inc): unit records instead of a block map
+    QUnit *q_dev = nullptr, *q_pin = nullptr;
+    int q_units = -1;            // -1: this size takes the per-block form
+    int q_bbf_prob = 0, q_bbf_blocks = 0, q_bbf_tiles = 0;
     hipEvent_t landed = nullptr;
     hipStream_t up_stream = nullptr;   // the stream the upload went out on: a hit from ANOTHER stream waits for `landed` first
     uint64_t stamp = 0;
@@ -84,6 +88,7 @@ struct Conv3Group {
     int64_t map_capacity = 0;    // blocks at max_batch
     MapSlot slot[kMapSlots];
     std::vector<int2> map_host;  // scratch of group_blocks()
+    std::vector<QUnit> units_host;   // scratch of queue_plan()
 };
 
 // a set of independent convolutions on the generic kernel issued as ONE launch (kernels.hip: conv_direct_group_kernel)
@@ -214,6 +219,15 @@ struct hrn_ctx {
     bool disable_f32lds = getenv("HRN_DISABLE_F32LDS") != nullptr;   // fp32 3x3 stride-1 convs back on the generic kernel
     int f32_small_slices = getenv("HRN_F32_SMALL_SLICES") ? atoi(getenv("HRN_F32_SMALL_SLICES")) : 0;   // fp32: 128-pixel tiles from this many slices on (0: never; 4 and 8 measured: no gain)
     // stride-2 slab kernel (conv_s2.hip) off: those convolutions stay on the generic kernel (bit-identical results)
+    // persistent work-queue form of the grouped BasicBlock launches (round 4): off with HRN_QUEUE=0; tiles per unit; scale of the
+    // share of the CUs that start on the fused 48-channel range; fewest units per CU for a launch to take the form
+    bool queue_on = !(getenv("HRN_QUEUE") && atoi(getenv("HRN_QUEUE")) == 0);
+    int queue_tpb = getenv("HRN_Q_TPB") ? std::max(1, atoi(getenv("HRN_Q_TPB"))) : 1;
+    double queue_bbf_scale = getenv("HRN_Q_BBF_SCALE") ? atof(getenv("HRN_Q_BBF_SCALE")) : 1.0;
+    int queue_min_units_per_cu = getenv("HRN_Q_MIN_UNITS") ? atoi(getenv("HRN_Q_MIN_UNITS")) : 2;
+    int num_cus = 256;
+    int *qheads_dev = nullptr;   // 16 ints per grouped launch (8 used: one list head per XCD), zeroed at the start of every pass
+    std::vector<Conv3Problem> probs_host;
     bool disable_s2 = getenv("HRN_DISABLE_S2") != nullptr;
     // the slab kernel is taken when a launch has at least this many tiles (one per CU); smaller calls use the generic kernel
     int s2_min_tiles = getenv("HRN_S2_MIN_TILES") ? atoi(getenv("HRN_S2_MIN_TILES")) : 256;
@@ -791,7 +805,7 @@ struct hrn_ctx {
         const int64_t part = (int64_t)max_batch * joints * head_slabs;
         workspace_bytes += part * 8;
         if (plan_only) {
-            index_groups();
+            fill_problems();
             index_s2groups();
             blob = (char *)calloc(1, (size_t)blob_bytes);
             return blob != nullptr;
@@ -933,6 +947,72 @@ struct hrn_ctx {
             for (size_t i = 0; i < ents.size(); ++i) (*out)[i] = ents[i].v;
         }
         return (int)ents.size();
+    }
+
+    // The persistent work-queue form of a grouped launch for a call of nb crops (conv3x3_queue.inc): the units are the block
+    // map's entries (same order: longest first, XCD-aware inside a convolution) with `queue_tpb` M tiles each; the fused
+    // BasicBlock of the launch (at most one: the 48-channel branch) is not queued -- `bbf_blocks` of the CUs each take an equal
+    // range of its tiles first.  Returns false when the launch has to take the per-block form: a member that is neither a
+    // 96-cout-form convolution on 512-pixel tiles nor the fused block, 128-pixel tiles, too few units to pay.
+    bool queue_plan(const Conv3Group &g, int nb, bool reverse, std::vector<QUnit> *units, int *bbf_prob, int *bbf_blocks, int *bbf_tiles,
+                    std::vector<int> *unit_conv = nullptr, int *bbf_conv = nullptr) const {
+        if (!queue_on || dtype != HRN_BF16 || probs_host.empty()) return false;
+        *bbf_prob = 0, *bbf_blocks = 0, *bbf_tiles = 0;
+        struct Ent {
+            double key;
+            QUnit u;
+            int conv;
+        };
+        std::vector<Ent> ents;
+        double cost_bbf = 0, cost_q = 0;
+        if (bbf_conv) *bbf_conv = -1;
+        int nfused = 0;
+        for (size_t k = 0; k < g.conv_idx.size(); ++k) {
+            const ConvOp &cv = convs[g.conv_idx[k]];
+            if (skipped(cv, nb)) continue;
+            const Tensor &to = tensors[cv.out_t];
+            const int mtiles = (nb * to.hpwp + 511) / 512;
+            if (fused_now(cv, nb)) {
+                if (++nfused > 1) return false;
+                *bbf_prob = g.fused_prob[k], *bbf_tiles = mtiles;
+                if (bbf_conv) *bbf_conv = g.conv_idx[k];
+                cost_bbf = mtiles * 28000.0;
+                continue;
+            }
+            if (!cv.n96 || cv.slices < 3 || conv3x3_lds_bm(cv.ks, cv.nr, to.wp) != 512) return false;
+            const Conv3Problem &pr = probs_host[g.prob_first + k];
+            const double tile_cost = cv.slices * 3.0 * 3900.0 + 2000.0;
+            const int tpb = queue_tpb;
+            const int mgroups = (mtiles + tpb - 1) / tpb;
+            int seq = 0;
+            // XCD-aware order inside a convolution (see group_blocks): rounds of 8 M groups x all cout tiles, M group fastest
+            for (int round = 0; round * 8 < mgroups; ++round)
+                for (int nt = 0; nt < cv.ntiles; ++nt)
+                    for (int x = 0; x < 8; ++x) {
+                        const int mg = round * 8 + x;
+                        if (mg >= mgroups) continue;
+                        int tiles = std::min(tpb, mtiles - mg * tpb);
+                        int mt0 = mg * tpb;
+                        if (reverse) mt0 = mtiles - mt0 - tiles;
+                        ents.push_back({-tiles * tile_cost + 1e-9 * seq++, make_qunit(pr, nt, mt0, tiles, nb), g.conv_idx[k]});
+                        cost_q += tiles * tile_cost;
+                    }
+        }
+        if ((long)ents.size() < (long)queue_min_units_per_cu * num_cus) return false;
+        std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
+        if (nfused) {
+            int nbb = (int)(num_cus * queue_bbf_scale * cost_bbf / (cost_bbf + cost_q) / 8.0 + 0.5) * 8;   // whole XCD rounds
+            *bbf_blocks = std::max(8, std::min(num_cus - 8, nbb));
+        }
+        if (units) {
+            units->resize(ents.size());
+            for (size_t i = 0; i < ents.size(); ++i) (*units)[i] = ents[i].u;
+        }
+        if (unit_conv) {
+            unit_conv->resize(ents.size());
+            for (size_t i = 0; i < ents.size(); ++i) (*unit_conv)[i] = ents[i].conv;
+        }
+        return true;
     }
 
     // the pixel grid a convolution iterates over: its output, or for a transposed-conv phase its input
@@ -1139,6 +1219,8 @@ struct hrn_ctx {
         if (sl.pin) (void)hipHostFree(sl.pin);
         if (sl.args_dev) (void)hipFree(sl.args_dev);
         if (sl.args_pin) (void)hipHostFree(sl.args_pin);
+        if (sl.q_dev) (void)hipFree(sl.q_dev);
+        if (sl.q_pin) (void)hipHostFree(sl.q_pin);
         if (sl.landed) (void)hipEventDestroy(sl.landed);
         sl = MapSlot();
     }
@@ -1183,10 +1265,12 @@ struct hrn_ctx {
         return nprob;
     }
 
-    bool setup_groups() {
+    // the descriptors of the grouped launches on the host (plan-only handles: the same, with the pointers of an unallocated
+    // workspace -- hrn_plan_queue reads the geometry only)
+    size_t fill_problems() {
         const size_t nprob = index_groups();
-        if (!nprob) return true;
-        std::vector<Conv3Problem> hp(nprob);
+        probs_host.assign(nprob, Conv3Problem{});
+        std::vector<Conv3Problem> &hp = probs_host;
         for (auto &g : groups) {
             g.max_wp = 0;
             for (size_t k = 0; k < g.conv_idx.size(); ++k) {
@@ -1213,6 +1297,15 @@ struct hrn_ctx {
                     f.w2 = blob + c2.w_off, f.bias2 = (const float *)(blob + c2.b_off);
                 }
             }
+        }
+        return nprob;
+    }
+
+    bool setup_groups() {
+        const size_t nprob = fill_problems();
+        if (!nprob) return true;
+        std::vector<Conv3Problem> &hp = probs_host;
+        for (auto &g : groups) {
             g.map_capacity = 64 + 4 * (int64_t)std::max(small_below, 256) + 1024;  // one M tile per block = most blocks any split can produce (+ the small-tile mode)
             for (int ci : g.conv_idx) {
                 const ConvOp &cv = convs[ci];
@@ -1223,7 +1316,18 @@ struct hrn_ctx {
             for (MapSlot &sl : g.slot) {
                 if (!alloc_slot(sl, g.map_capacity, 0)) return false;
                 workspace_bytes += g.map_capacity * (int64_t)sizeof(int2);
+                if (queue_on && dtype == HRN_BF16) {
+                    if (!hip_ok(hipMalloc((void **)&sl.q_dev, (size_t)g.map_capacity * sizeof(QUnit)), "hipMalloc(queue units)")) return false;
+                    if (!hip_ok(hipHostMalloc((void **)&sl.q_pin, (size_t)g.map_capacity * sizeof(QUnit), hipHostMallocDefault), "hipHostMalloc(queue units)"))
+                        return false;
+                    workspace_bytes += g.map_capacity * (int64_t)sizeof(QUnit);
+                }
             }
+        }
+        if (queue_on && dtype == HRN_BF16) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) num_cus = prop.multiProcessorCount;
+            if (!hip_ok(hipMalloc((void **)&qheads_dev, groups.size() * 16 * sizeof(int)), "hipMalloc(queue heads)")) return false;
         }
         if (!hip_ok(hipMalloc((void **)&probs_dev, nprob * sizeof(Conv3Problem)), "hipMalloc(problems)")) return false;
         return hip_ok(hipMemcpy(probs_dev, hp.data(), nprob * sizeof(Conv3Problem), hipMemcpyHostToDevice),
@@ -1250,6 +1354,7 @@ struct hrn_ctx {
             if (part_val) (void)hipFree(part_val);
             if (part_idx) (void)hipFree(part_idx);
             if (probs_dev) (void)hipFree(probs_dev);
+            if (qheads_dev) (void)hipFree(qheads_dev);
             if (s2probs_dev) (void)hipFree(s2probs_dev);
             for (auto &g : s2groups)
                 for (MapSlot &sl : g.slot) free_slot(sl);
@@ -1517,6 +1622,8 @@ struct hrn_ctx {
     bool run_pass(const float *images, int nb, const void *boxes, int box_dtype, float *pts, float *heatmaps,
                   hipStream_t s, Timing *tm, int flip = 0, const TapReq *tap = nullptr) {
         if (tm && !hip_ok(hipEventRecord(tm->ev[0], s), "hipEventRecord")) return false;
+        // the list heads of every work-queue launch of the pass, in one go (each launch has its own eight)
+        if (qheads_dev && !hip_ok(hipMemsetAsync(qheads_dev, 0, groups.size() * 16 * sizeof(int), s), "hipMemsetAsync(queue heads)")) return false;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             // every other launch walks its tensors backwards: it starts on what its producer wrote last, i.e. on the
             // part most likely still in the Infinity Cache (256 MB; a 256-crop tensor is up to 0.9 GB)
@@ -1585,16 +1692,32 @@ struct hrn_ctx {
             MapSlot *sl = find_slot(g.slot, nb, &hit);
             if ((e = slot_ready(sl, hit, s)) != hipSuccess) break;
             if (!hit) {  // block map depends on the micro-batch size: build it once per size (kMapSlots sizes kept)
-                sl->nblocks = group_blocks(g, nb, &g.map_host, rev);
-                memcpy(sl->pin, g.map_host.data(), (size_t)sl->nblocks * sizeof(int2));
-                e = hipMemcpyAsync(sl->dev, sl->pin, (size_t)sl->nblocks * sizeof(int2), hipMemcpyHostToDevice, s);
+                sl->q_units = -1;
+                if (sl->q_dev && queue_plan(g, nb, rev, &g.units_host, &sl->q_bbf_prob, &sl->q_bbf_blocks, &sl->q_bbf_tiles) &&
+                    (int64_t)g.units_host.size() <= g.map_capacity) {
+                    sl->q_units = (int)g.units_host.size();
+                    memcpy(sl->q_pin, g.units_host.data(), (size_t)sl->q_units * sizeof(QUnit));
+                    e = hipMemcpyAsync(sl->q_dev, sl->q_pin, (size_t)sl->q_units * sizeof(QUnit), hipMemcpyHostToDevice, s);
+                } else {
+                    sl->nblocks = group_blocks(g, nb, &g.map_host, rev);
+                    if (sl->nblocks > g.map_capacity) {   // (never write past the slot)
+                        e = hipErrorInvalidValue;
+                        break;
+                    }
+                    memcpy(sl->pin, g.map_host.data(), (size_t)sl->nblocks * sizeof(int2));
+                    e = hipMemcpyAsync(sl->dev, sl->pin, (size_t)sl->nblocks * sizeof(int2), hipMemcpyHostToDevice, s);
+                }
                 if (e == hipSuccess) e = hipEventRecord(sl->landed, s);
                 if (e != hipSuccess) break;
                 sl->nb = nb;
                 ++map_builds;
             }
-            e = launch_conv3x3_lds(probs_dev + g.prob_first, sl->dev, sl->nblocks, nb, convs[g.conv_idx[0]].ks,
-                                   convs[g.conv_idx[0]].nr, s);
+            if (sl->q_units >= 0)
+                e = launch_conv3x3_queue(sl->q_dev, sl->q_units, qheads_dev + 16 * op.idx, probs_dev + g.prob_first, sl->q_bbf_prob, sl->q_bbf_blocks,
+                                         sl->q_bbf_tiles, rev ? 1 : 0, nb, num_cus, s);
+            else
+                e = launch_conv3x3_lds(probs_dev + g.prob_first, sl->dev, sl->nblocks, nb, convs[g.conv_idx[0]].ks,
+                                       convs[g.conv_idx[0]].nr, s);
             break;
         }
         case OP_CONV_GROUP: {
@@ -2137,6 +2260,21 @@ double hrn_flops_per_crop(hrn_handle h) {
 int64_t hrn_workspace_bytes(hrn_handle h) { return h ? h->workspace_bytes : 0; }
 int64_t hrn_map_rebuilds(hrn_handle h) { return h ? h->map_builds : -1; }
 int hrn_launches_per_pass(hrn_handle h) { return h ? (int)h->ops.size() : 0; }
+
+int hrn_plan_queue(hrn_handle h, int group, int n, int reverse, int32_t *units, int capacity, int32_t *info) {
+    if (!h || n <= 0 || n > h->max_batch) return -1;
+    if (group < 0 || group >= (int)h->groups.size()) return -1;
+    std::vector<QUnit> u;
+    std::vector<int> uc;
+    int bbf_prob = 0, bbf_blocks = 0, bbf_tiles = 0, bbf_conv = -1;
+    if (!h->queue_plan(h->groups[group], n, reverse != 0, &u, &bbf_prob, &bbf_blocks, &bbf_tiles, &uc, &bbf_conv)) return -2;
+    for (size_t i = 0; i < u.size() && (int)i < capacity; ++i) {
+        int32_t *o = units + i * 4;
+        o[0] = uc[i], o[1] = u[i].ch_base / 96, o[2] = u[i].mt0, o[3] = u[i].ntile;
+    }
+    if (info) info[0] = bbf_conv, info[1] = bbf_blocks, info[2] = bbf_tiles, info[3] = h->num_cus;
+    return (int)u.size();
+}
 
 int hrn_plan_block_map(hrn_handle h, int group, int n, int reverse, int32_t *blocks, int capacity, int32_t *members, int member_capacity) {
     if (!h || n <= 0 || n > h->max_batch) return -1;

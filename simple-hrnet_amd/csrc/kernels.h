@@ -58,6 +58,39 @@ struct Conv3Problem {
     // 96-cout form (conv3x3_n96.inc): KS = 32, ntiles = cout / 96, bm = 512 or 384
     int n96;
 };
+// Persistent work-queue form of a grouped launch (conv3x3_queue.inc): one unit = (convolution, 96-cout tile, run of 512-pixel
+// M tiles), everything a block needs to know about it in ONE 128-byte record (fetched by LDS-DMA, 8 lanes x 16 bytes).
+struct QUnit {
+    const void *in;      // row 0 of the input tensor
+    const void *w;       // packed weights of this cout tile: [slice][3 stages][18 KiB]
+    const float *bias;   // the 96 folded biases of this cout tile
+    void *out;           // row 0 of the output tensor
+    const void *res;     // row 0 of the residual tensor, or nullptr
+    int cin;             // channels per row (= cout)
+    int wp, hpwp, h, wd;
+    int relu, slices;
+    int mt0, ntile;      // first M tile, M tiles of this unit
+    int ch_base;         // first output channel of the cout tile
+    int m;               // rows of the tensors = crops * hpwp
+    unsigned magic_hpwp, magic_wp;
+    int shift_hpwp, shift_wp;
+    int pad_[7];
+};
+// the record of unit (cout tile nt, M tiles [mt0, mt0 + ntile)) of a 96-cout-form convolution for a call of nb crops
+inline QUnit make_qunit(const Conv3Problem &p, int nt, int mt0, int ntile, int nb) {
+    QUnit u{};
+    u.in = p.in, u.out = p.out, u.res = p.res;
+    u.w = (const char *)p.w + (size_t)nt * p.slices * 3 * (3 * 6 * 1024);   // [cout tile][slice][3 stages][18 KiB]
+    u.bias = p.bias + nt * 96;
+    u.cin = p.cin, u.wp = p.wp, u.hpwp = p.hpwp, u.h = p.h, u.wd = p.wd, u.relu = p.relu, u.slices = p.slices;
+    u.mt0 = mt0, u.ntile = ntile, u.ch_base = nt * 96, u.m = nb * p.hpwp;
+    u.magic_hpwp = p.magic_hpwp, u.magic_wp = p.magic_wp, u.shift_hpwp = p.shift_hpwp, u.shift_wp = p.shift_wp;
+    return u;
+}
+// blocks per launch = CUs; heads_dev: 8 zeroed ints (one list head per XCD); blocks [0, bbf_blocks) first run an equal share of
+// the bbf_tiles fused-BasicBlock tiles of descriptor probs_dev[bbf_prob]
+hipError_t launch_conv3x3_queue(const QUnit *qunits_dev, int nunits, int *heads_dev, const Conv3Problem *probs_dev, int bbf_prob,
+                                int bbf_blocks, int bbf_tiles, int rev, int nb, int nblocks, hipStream_t s);
 int conv3x3_n96_ch64();           // output-channel permutation of the 96-cout form's weight image (conv3x3_n96.inc)
 int conv3x3_lds_bbf_ok(int wp);  // the fused BasicBlock kernel fits this row pitch
 int conv3x3_lds_bm(int ks, int nrb, int wp);  // (32, 6) = the 96-cout form; ks = 16: the fp32 kernel (conv3x3_f32.hip)
