@@ -219,11 +219,12 @@ struct hrn_ctx {
     bool disable_f32lds = getenv("HRN_DISABLE_F32LDS") != nullptr;   // fp32 3x3 stride-1 convs back on the generic kernel
     int f32_small_slices = getenv("HRN_F32_SMALL_SLICES") ? atoi(getenv("HRN_F32_SMALL_SLICES")) : 0;   // fp32: 128-pixel tiles from this many slices on (0: never; 4 and 8 measured: no gain)
     // stride-2 slab kernel (conv_s2.hip) off: those convolutions stay on the generic kernel (bit-identical results)
-    // persistent work-queue form of the grouped BasicBlock launches (round 4): off with HRN_QUEUE=0; tiles per unit; scale of the
-    // share of the CUs that start on the fused 48-channel range; fewest units per CU for a launch to take the form
-    bool queue_on = !(getenv("HRN_QUEUE") && atoi(getenv("HRN_QUEUE")) == 0);
+    // persistent work-queue form of the grouped BasicBlock launches (round 4; bit-identical to the per-block form and, measured
+    // in the net, no faster: profiles/EXPERIMENTS.md -- so it is an option, HRN_QUEUE=1, not the default); tiles per unit; scale of
+    // the share of the CUs that start on the fused 48-channel range; fewest units per CU for a launch to take the form
+    bool queue_on = getenv("HRN_QUEUE") && atoi(getenv("HRN_QUEUE")) != 0;
     int queue_tpb = getenv("HRN_Q_TPB") ? std::max(1, atoi(getenv("HRN_Q_TPB"))) : 1;
-    double queue_bbf_scale = getenv("HRN_Q_BBF_SCALE") ? atof(getenv("HRN_Q_BBF_SCALE")) : 1.0;
+    double queue_bbf_scale = getenv("HRN_Q_BBF_SCALE") ? atof(getenv("HRN_Q_BBF_SCALE")) : 1.2;
     int queue_min_units_per_cu = getenv("HRN_Q_MIN_UNITS") ? atoi(getenv("HRN_Q_MIN_UNITS")) : 2;
     int num_cus = 256;
     int *qheads_dev = nullptr;   // 16 ints per grouped launch (8 used: one list head per XCD), zeroed at the start of every pass

@@ -28,7 +28,8 @@ def _plan(net, n, reverse):
 
 
 @pytest.mark.parametrize("n,reverse", [(256, 0), (256, 1), (200, 0), (97, 1)])
-def test_queue_units_cover_every_tile_once(n, reverse):
+def test_queue_units_cover_every_tile_once(monkeypatch, n, reverse):
+    monkeypatch.setenv("HRN_QUEUE", "1")
     pkg = load_pkg()
     net = pkg.NativeHRNet(48, 17, (384, 288), "bf16", max_batch=256, device=-1)
     infos = net.conv_infos()
@@ -59,13 +60,18 @@ def test_queue_units_cover_every_tile_once(n, reverse):
     net.close()
 
 
-def test_small_calls_take_the_per_block_form():
+def test_small_calls_take_the_per_block_form(monkeypatch):
+    monkeypatch.setenv("HRN_QUEUE", "1")
     pkg = load_pkg()
     net = pkg.NativeHRNet(48, 17, (384, 288), "bf16", max_batch=256, device=-1)
     assert all(nu == -2 for nu, _, _ in _plan(net, 8, 0))
     net.close()
     net = pkg.NativeHRNet(32, 17, (256, 192), "fp32", max_batch=64, device=-1)     # fp32 mode: never
     assert all(nu == -2 for nu, _, _ in _plan(net, 64, 0))
+    net.close()
+    monkeypatch.delenv("HRN_QUEUE")                                                # the form is an option, not the default
+    net = pkg.NativeHRNet(48, 17, (384, 288), "bf16", max_batch=256, device=-1)
+    assert all(nu == -2 for nu, _, _ in _plan(net, 256, 0))
     net.close()
 
 
@@ -82,10 +88,9 @@ def test_queue_form_is_bit_identical_to_the_per_block_form(monkeypatch, h, w, n,
         for k in ("HRN_QUEUE", "HRN_Q_TPB", "HRN_Q_BBF_SCALE", "HRN_Q_MIN_UNITS"):
             monkeypatch.delenv(k, raising=False)
         if on:
+            monkeypatch.setenv("HRN_QUEUE", "1")
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
-        else:
-            monkeypatch.setenv("HRN_QUEUE", "0")
         net = pkg.NativeHRNet(48, 17, (h, w), "bf16", max_batch=256, device=0).load_state_dict(state_dict_np(48))
         nq = sum(1 for nu, _, _ in _plan(net, n, 0) if nu >= 0)
         assert (nq > 0) == on
