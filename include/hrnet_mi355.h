@@ -214,7 +214,13 @@ int64_t hrn_workspace_bytes(hrn_handle h);
  * n is not a multiple of max_batch: SimpleHRNet.py:285-294 runs a short last chunk) stops rebuilding after its first
  * pass over each size -- the test of that property reads this counter. */
 int64_t hrn_map_rebuilds(hrn_handle h);
+/* The number of entries of the static launch list (grouped launches count once).  A small call may issue more kernels: a
+ * stride-2 slab group with too few tiles runs its convolutions on the generic kernel (one or more launches), a debug tap adds one. */
 int hrn_launches_per_pass(hrn_handle h);
+/* The HRN_* environment switches (same-box A/B runs, bit-identity tests) this handle saw when it was
+ * created, as "NAME=value;..." -- "" in production.  They are read at hrn_create only, never during a call, and not at all
+ * when HRN_IGNORE_ENV=1 is set (release mode: the library's behaviour does not depend on the caller's environment). */
+const char *hrn_switches(hrn_handle h);
 /* Block map of the `group`-th grouped BasicBlock launch for a call of n crops, as the host would upload it (works on
  * plan-only handles: the CPU tests check that every (conv, cout tile, M tile) is covered exactly once).  Per block six
  * int32: descriptor, cout tile, M tiles walked, first M tile, pixels per M tile, flags (1 = fused BasicBlock, 2 =

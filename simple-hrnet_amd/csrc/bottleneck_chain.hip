@@ -215,7 +215,7 @@ static hipError_t launch_chain_t(const ChainArgs &a, hipStream_t s) {
         attr_set = true;
     }
     // persistent: 8 waves per CU re-use their staged weights over many 16-pixel fragments
-    static const int blocks_env = getenv("HRN_CHAIN_BLOCKS") ? atoi(getenv("HRN_CHAIN_BLOCKS")) : 512;
+    static const int blocks_env = hrn_env("HRN_CHAIN_BLOCKS") ? atoi(hrn_env("HRN_CHAIN_BLOCKS")) : 512;
     constexpr int WAVES = DS ? 8 : 4;
     const int mfrags = (a.m + 15) / 16;
     int blocks = (mfrags + WAVES - 1) / WAVES;

@@ -16,6 +16,9 @@
 //     has no weight traffic at all, no barrier, and one ds_read_b128 per three MFMAs; the slab crosses L2 -> LDS once per
 //     tile for all 192 couts.
 //   * two slab buffers (2 x 78 KiB): the next tile's slab lands while this one is computed; one barrier per tile.
+//   * only REAL output rows are written (pad column included, as zeros); the pad row below an image's last row and the tail
+//     guard rows are never touched -- they keep the zeros the buffer was allocated with (the workspace invariant stated at
+//     hrn_ctx::new_tensor, ctx_plan.inc: buffers are zeroed once and reused by tensors of one geometry only).
 // K order and MFMA operand layout are those of the generic kernel (k = tap*48 + ci in 32-wide chunks, accumulators from
 // zero, bias added in the epilogue), so results are BIT-IDENTICAL to conv_direct_kernel on the same convolution -- which is
 // how the small-call fallback (too few tiles to fill the chip -> generic kernel) keeps a crop's result independent of the

@@ -4,7 +4,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+#include <cstring>
+
 namespace hrn {
+
+// The HRN_* environment switches exist for same-box A/B runs and the bit-identity tests.  They are read
+// ONCE, when a handle is created (hrn_create snapshots what it saw: hrn_switches()), never during a call -- and not at all when
+// HRN_IGNORE_ENV=1 is set: the release mode, in which the library's behaviour does not depend on the caller's environment.
+inline const char *hrn_env(const char *name) {
+    static const bool ignore = [] {
+        const char *v = getenv("HRN_IGNORE_ENV");
+        return v && *v && strcmp(v, "0") != 0;
+    }();
+    return ignore ? nullptr : getenv(name);
+}
 
 enum { DT_F32 = 0, DT_BF16 = 1 };
 
@@ -97,7 +111,7 @@ int conv3x3_lds_bm(int ks, int nrb, int wp);  // (32, 6) = the 96-cout form; ks 
 int conv3x3_f32_bm(int wp);
 hipError_t launch_conv3x3_f32(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb, int nrb, hipStream_t s);
 
-// Stride-2 slab kernel (conv_s2.hip): every 3x3 / stride-2 convolution with 48 (or 96) input channels that reads ONE tensor at
+// Stride-2 slab kernel (conv_s2.hip): every 3x3 / stride-2 convolution with 48 (HRNet-W32: 32 / 64) input channels that reads ONE tensor at
 // one fuse level contributes "parts" (48 (32) output channels each) to one problem; a block stages the input slab of `rows`
 // output rows once and its waves keep the parts' weights in registers.
 constexpr int kS2SlabBytes = 79872;   // one slab buffer: 832 sub-slots of 96 bytes (two of them + the biases fill the 160 KiB)

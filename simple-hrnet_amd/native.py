@@ -392,6 +392,10 @@ class NativeHRNet:
     def launches_per_pass(self) -> int:
         return int(self._lib.hrn_launches_per_pass(self._h))
 
+    def switches(self) -> str:
+        """the HRN_* environment switches this engine saw when it was created ("" in production; HRN_IGNORE_ENV=1: always "")"""
+        return self._lib.hrn_switches(self._h).decode()
+
     def profile_pass(self, images: torch.Tensor):
         """HIP-event time of every kernel of ONE internal pass over ``images[:max_batch]``.
         Returns (conv_ms[list], other_ms{stem,fuse,head,decode})."""

@@ -151,3 +151,19 @@ def test_nms_restores_the_callers_device_and_releases_scratch():
     assert lib.hrn_nms_release(0) == 0
     assert torch.cuda.mem_get_info(0)[0] >= free0
     np.testing.assert_array_equal(nms.gpu_nms(d, 0.5, 0), keep)     # scratch comes back on demand
+
+
+def test_release_mode_ignores_the_environment_and_handles_snapshot_their_switches():
+    """the HRN_* switches are read once per handle (hrn_switches says which it saw) and not at all under
+    HRN_IGNORE_ENV=1 -- checked in fresh processes, the flag being read once per process."""
+    import subprocess, sys
+    code = ("import importlib, sys; sys.path.insert(0, %r); pkg = importlib.import_module('simple-hrnet_amd');"
+            "net = pkg.NativeHRNet(48, 17, (384, 288), 'bf16', max_batch=256, device=-1);"
+            "print(repr(net.switches()), sum(i.algo == 3 for i in net.conv_infos()))" % ROOT)
+    outs = []
+    for env in ({"HRN_DISABLE_N96": "1"}, {"HRN_DISABLE_N96": "1", "HRN_IGNORE_ENV": "1"}, {}):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("HRN_")}
+        e.update(env)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120).stdout.strip())
+    assert outs[0] == "'HRN_DISABLE_N96=1;' 0"
+    assert outs[1] == outs[2] == "'' 144"
