@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_pkg, state_dict_np
+from conftest import ROOT, load_pkg, state_dict_np
 
 
 # --------------------------------------------------------------------------------------------- device mapping (CPU)
