@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--no-peaked", action="store_true", help="skip parity.peaked (bf16 px-match on the peaked checkpoint)")
     ap.add_argument("--no-fp32-w48", action="store_true", help="skip the fp32 line on the headline shape")
     ap.add_argument("--clip", action="store_true", help="ONLY the configs[4] clip measurement (its JSON line is the clip block)")
+    ap.add_argument("--check-gather", action="store_true", help="N > 1: compare the all-gathered joints with one engine run over every rank's crops")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -623,7 +624,8 @@ def self_launch(a):
     import torch
 
     have = torch.cuda.device_count()
-    if have < a.gpus:
+    # (HRN_BENCH_DEVICES="0,0": ranks share the listed devices -- the 2-rank test on a 1-GPU box; then the backend must be gloo)
+    if have < a.gpus and not os.environ.get("HRN_BENCH_DEVICES"):
         raise SystemExit("--gpus %d but only %d GPU(s) visible" % (a.gpus, have))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -657,6 +659,11 @@ def main():
     if a.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    # rank -> device: LOCAL_RANK, or the HRN_BENCH_DEVICES list (test hook: two ranks on ONE GPU, which RCCL refuses -- the
+    # backend is then HRN_BENCH_BACKEND=gloo and device tensors are staged through the host, as dist.ShardedHRNet does)
+    devmap = [int(x) for x in os.environ["HRN_BENCH_DEVICES"].split(",")] if os.environ.get("HRN_BENCH_DEVICES") else None
+    local = devmap[rank % len(devmap)] if devmap else local
+    backend = os.environ.get("HRN_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -665,7 +672,25 @@ def main():
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def reduce_max(x):       # a python float, MAX over the ranks
+        if not dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_floats(x):    # one python float per rank
+        if not dist:
+            return [x]
+        mine = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allr = torch.empty((world,), dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(allr, mine)
+        return [float(v) for v in allr.cpu()]
 
     pkg = importlib.import_module("simple-hrnet_amd")
     shard = importlib.import_module("simple-hrnet_amd.dist")
@@ -723,16 +748,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    per_rank = [a.batch * a.steps / el_mine]
-    if dist:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-        mine = torch.tensor([a.batch * a.steps / el_mine], device=dev, dtype=torch.float64)
-        allr = torch.empty((world,), device=dev, dtype=torch.float64)
-        dist.all_gather_into_tensor(allr, mine)
-        per_rank = [float(x) for x in allr.cpu()]
+    el = reduce_max(el)
+    per_rank = gather_floats(a.batch * a.steps / el_mine)
     assert tuple(pts.shape) == (a.batch * world, 17, 3) and bool(torch.isfinite(pts).all())
+    # --check-gather: the gathered joints of ALL ranks against ONE engine run over every rank's crops on this rank's GPU (crops and
+    # boxes are seeded per rank, so any rank can regenerate them): what the sharding + all-gather must not change
+    gather_ok = None
+    if a.check_gather and world > 1:
+        ref = []
+        for r in range(world):
+            gr = torch.Generator(device=dev).manual_seed(1234 + r)
+            im = torch.randn((a.batch, 3, a.height, a.width), generator=gr, device=dev, dtype=torch.float32)
+            ref.append(net.predict_crops(im, torch.from_numpy(pkg.synth_boxes(a.batch, seed=100 + r)).to(dev)))
+        gather_ok = bool(torch.equal(torch.cat(ref, 0), pts))
+        gather_ok = reduce_max(0.0 if gather_ok else 1.0) == 0.0
     lanes_same = None
     if lanes_eng is not None:   # the lanes only reschedule: same joints as ONE engine on the same crops
         lanes_same = bool(torch.equal(pts[rank * a.batch:(rank + 1) * a.batch], net.predict_crops(images, boxes)))
@@ -759,7 +788,9 @@ def main():
                        "lanes_per_gpu": 1 if lanes_eng is None else a.lanes, "lanes_same_joints_as_one_engine": lanes_same,
                        "parallelism": "dp%d (crop sharding, RCCL all-gather of keypoints)" % world,
                        "weights": "random-init seeded (synth_state_dict seed 0), BN stats randomised"},
-            "rccl_ranks": world if dist else 0,
+            "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0) if dist else 0,
+            "collective_backend": (dist.get_backend() if dist else None),
+            "gathered_joints_equal_single_engine": gather_ok,
             "per_rank_crops_per_s": [round(x, 1) for x in per_rank],
             "whole_net_tflops": round(value / world * flops / 1e12, 2),
             "gflop_per_crop": round(flops / 1e9, 3),
