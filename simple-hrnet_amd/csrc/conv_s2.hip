@@ -9,7 +9,9 @@
 //     virtual input rows 2*h0-1 .. 2*(h0+R-1)+1, each from column -1 to column W -- is staged ONCE per block in LDS by
 //     LDS-DMA, de-interleaved by column parity on the way in: slot(vrow, plane, j) holds input column 2*j-1+plane, so the
 //     16 pixels of a fragment are 16 consecutive 96-byte slots for every tap (96 = 32 mod 64 dwords*4: conflict-free, like
-//     the stride-1 slab) and a tap is a constant slot shift  dh*2*Wop + (dw&1)*Wop + (dw>>1).
+//     the stride-1 slab) and a tap is a constant slot shift  dh*2*Wop + (dw&1)*Wop + (dw>>1).  Round 4: an output row's two
+//     virtual rows are followed by 0..7 pad slots (kernels.h: s2_pair_pad) so that a fragment that WRAPS an output row keeps
+//     its 16 slot numbers consecutive mod 8 -- without them such fragments conflicted (32 % of the LDS cycles).
 //   * N = ALL output channels of ALL convolutions that read this tensor at this fuse level (the 48->96 and the two 48->48
 //     first convs of a stage-4 module: 192 couts), split over the waves in groups of 48: a wave keeps its group's whole
 //     weight matrix (48 x 432 -> 14 K chunks x 3 fragments = 168 VGPRs) IN REGISTERS for the block's lifetime, so the K loop
@@ -85,6 +87,7 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
     // ---- LDS-DMA of a slab, one 1-KiB piece (64 lanes x 16 bytes) per call.  Piece k of a wave: half k / NSPH, units
     //      (k % NSPH) * 512 + wave * 64 ... of that half's region; unit u = sub-slot u / 6, 16-byte piece u % 6
     const int slots_per_vrow = 2 * Wop;
+    const int pair_pitch = s2_pair_pitch(Wop);   // slots per output row: two virtual rows + the bank pad (kernels.h)
     struct Slab {
         const GLOBAL_AS char *src;
         char *dst;
@@ -95,7 +98,7 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
         const int h0 = rg * R;
         const int rt = Ho - h0 < R ? Ho - h0 : R;
         Slab sl;
-        sl.units = (2 * rt + 1) * slots_per_vrow * UPR;
+        sl.units = (rt * pair_pitch + slots_per_vrow) * UPR;   // rt row pairs + the first virtual row of the next pair
         // first pixel of the slab: row 2*h0 - 1, column -1 of image n (guard rows / the previous image's pad row when h0 == 0)
         const long px0 = (long)n * in_hpwp + (long)(2 * h0 - 1) * in_wp - 1;
         sl.src = in + px0 * (CIN * 2);
@@ -109,7 +112,13 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
             if (u >= sl.units) u = sl.units - 1;  // tail lanes re-read a valid unit (their LDS slots lie inside the region, unused)
             const int slot = UPR == 6 ? (int)(((unsigned)u * 43691u) >> 18) : u / UPR;  // u / 6 for u < 2^15 (UPR 2: a shift)
             const int pc = u - slot * UPR;
-            const int vrow = slot / slots_per_vrow, rem = slot - vrow * slots_per_vrow;
+            // slot -> (virtual row, column parity plane, j): row pair slot / pair_pitch, then its first row, its second row or the
+            // pad (those lanes fetch a valid pixel into slots nobody reads)
+            const int pair = slot / pair_pitch, o = slot - pair * pair_pitch;
+            const int second = o >= slots_per_vrow ? 1 : 0;
+            int rem = o - second * slots_per_vrow;
+            if (rem >= slots_per_vrow) rem = slots_per_vrow - 1;
+            const int vrow = 2 * pair + second;
             const int plane = rem >= Wop ? 1 : 0, j = rem - plane * Wop;
             const int rel = (vrow * in_wp + 2 * j + plane) * (CIN * 2) + half * ROWB + pc * 16;
             glds16(sl.src + rel, sl.dst + half * HALF_BYTES + (kk * NT + wave * 64) * 16);
@@ -156,7 +165,7 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
             if (k0 >= 9 * CIN) k0 = 0;   // zero weights: any valid slab address
             const int tap = k0 / CIN, ci = k0 - tap * CIN;
             const int dh = tap / 3, dw = tap - 3 * dh;
-            xoff[c] = (dh * slots_per_vrow + (dw & 1) * Wop + (dw >> 1)) * ROWB + ci * 2;
+            xoff[c] = ((dh == 2 ? pair_pitch : dh * slots_per_vrow) + (dw & 1) * Wop + (dw >> 1)) * ROWB + ci * 2;
         }
     } else {
 #pragma unroll
@@ -170,7 +179,7 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
             return (unsigned)xoff[c];
         } else {
             const int tap = c / CPT, dh = tap / 3, dw = tap - 3 * dh;
-            return (unsigned)((dh * slots_per_vrow + (dw & 1) * Wop + (dw >> 1)) * ROWB) + (unsigned)xoff[c % CPT];
+            return (unsigned)(((dh == 2 ? pair_pitch : dh * slots_per_vrow) + (dw & 1) * Wop + (dw >> 1)) * ROWB) + (unsigned)xoff[c % CPT];
         }
     };
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_s2;
@@ -218,7 +227,7 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
                     if (tt >= npx) tt = 0;   // dead lanes / a missing fragment: any valid pixel, never stored
                     const int rr = (int)(((unsigned long long)(unsigned)tt * magic_wop) >> shift_wop);
                     wo[i] = tt - rr * Wop;
-                    xa[i] = lds0 + b * kS2SlabBytes + (2 * rr * slots_per_vrow + wo[i]) * ROWB;
+                    xa[i] = lds0 + b * kS2SlabBytes + (rr * pair_pitch + wo[i]) * ROWB;
                 }
                 f32x4 acc[MW][NF];
 #pragma unroll

@@ -121,6 +121,12 @@ constexpr int s2_frags_per_part(int cin) { return cin == 48 ? 3 : 2; }   // 16-c
 constexpr int s2_subslot_bytes(int cin) { return cin % 48 == 0 ? 96 : 32; }
 constexpr int s2_region_bytes(int cin) { return kS2SlabBytes / (cin * 2 / s2_subslot_bytes(cin)) / 1024 * 1024; }
 constexpr int s2_slot_capacity(int cin) { return s2_region_bytes(cin) / s2_subslot_bytes(cin); }   // input pixels one slab buffer holds
+// The slab keeps TWO virtual input rows (4 wop slots: both column parities of both rows) + `pad` empty slots per output row, so
+// that the 16 pixels of a fragment that wraps an output row stay on disjoint LDS banks: the wrap jumps 3 wop + 1 + pad slots,
+// and sub-slots of 96 (32) bytes are conflict-free for 16 lanes iff their slot numbers are consecutive mod 8 (round 4: the
+// unpadded slab measured a 32 % LDS bank-conflict rate, profiles/round3_pmc_s2.txt).
+constexpr int s2_pair_pad(int wop) { return (8 - (3 * wop) % 8) % 8; }
+constexpr int s2_pair_pitch(int wop) { return 4 * wop + s2_pair_pad(wop); }   // slots per output row of the slab
 constexpr int kS2MaxParts = 8;
 struct S2Part {
     const void *w;      // [K chunks][frags][64 lanes][16 B]: the (cin, frags) image of pack_conv_lds for this cout tile (k = tap * cin + ci)
