@@ -360,6 +360,9 @@ def clip_measure(pkg, net, dist, rank, world, cpu_clip=None):
             res["per_frame_pipelined"] = {"fps": round(clip.shape[0] / el, 2), "persons_per_s": round(dets.shape[0] * dets.shape[1] / el, 1),
                                           "ms_per_frame": round(el / clip.shape[0] * 1e3, 3), "frames_in_flight": lanes,
                                           "same_joints_as_per_frame": bool(ref is not None and np.array_equal(pts, ref)),
+                                          "workspace_bytes_per_engine": int(smalls[0].workspace_bytes()),
+                                          "workspace_bytes_total": int(sum(sm.workspace_bytes() for sm in smalls)),
+                                          "weight_blob_bytes_per_engine": int(smalls[0].weight_blob_tensor().numel()),
                                           "note": "throughput with %d frames in flight on %d engines of one GPU; the latency of a frame is per_frame's" % (lanes, lanes)}
             for sm in smalls:
                 sm.close()
@@ -787,7 +790,8 @@ def main():
                        "global_batch": a.batch * world, "micro_batch": a.max_batch if lanes_eng is None else lanes_eng.max_batch,
                        "lanes_per_gpu": 1 if lanes_eng is None else a.lanes, "lanes_same_joints_as_one_engine": lanes_same,
                        "parallelism": "dp%d (crop sharding, RCCL all-gather of keypoints)" % world,
-                       "weights": "random-init seeded (synth_state_dict seed 0), BN stats randomised"},
+                       "weights": "random-init seeded (synth_state_dict seed 0), BN stats randomised",
+                       "engine_switches": net.switches()},
             "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0) if dist else 0,
             "collective_backend": (dist.get_backend() if dist else None),
             "gathered_joints_equal_single_engine": gather_ok,

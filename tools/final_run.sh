@@ -2,11 +2,11 @@
 # end-of-round evidence in one bounded call on the GPU box: GPU tests (with the per-op pin reports), the bench line, rocprofv3
 # kernel stats of the same command, the PMC traffic passes, one wave-state / matrix-pipe PMC pass for the graded kernel and
 # one for the stride-2 slab kernel.   tools/final_run.sh <round> <outdir under gpurun_out>
-round=${1:-3}; out=gpurun_out/${2:-final_r$round}
+round=${1:-4}; out=gpurun_out/${2:-final_r$round}
 cd "$(dirname "$0")/.."; R=$PWD; export TMPDIR=/tmp
 mkdir -p "$out"
-(timeout 1500 python -m pytest tests -m gpu -q -rP > "$out/gputest.log" 2>&1; echo "rc=$?" >> "$out/gputest.log") < /dev/null
-grep -E "bf16 pin|fp32 taps|passed|failed|rc=" "$out/gputest.log" | cut -c1-300 > "$out/round${round}_gputest_summary.txt"
+(timeout 1500 python -m pytest tests -m gpu -q -rP -rs > "$out/gputest.log" 2>&1; echo "rc=$?" >> "$out/gputest.log") < /dev/null
+grep -E "bf16 pin|fp32 taps|\[peaked|SKIPPED|passed|failed|rc=" "$out/gputest.log" | cut -c1-400 > "$out/round${round}_gputest_summary.txt"
 tail -n 3 "$out/round${round}_gputest_summary.txt"
 timeout 500 python bench.py > "$out/bench.json" 2> "$out/bench.err" < /dev/null
 python tools/abline.py bench "$out/bench.json" < /dev/null
@@ -22,3 +22,6 @@ python tools/pmc_mean.py "$CSV" "conv_s2_slab_kernel" > "$out/round${round}_pmc_
 python tools/pmc_mean.py "$CSV" "conv_direct" > "$out/round${round}_pmc_direct.txt" < /dev/null
 cat "$out/round${round}_pmc_wave.txt" "$out/round${round}_pmc_s2.txt"
 rm -rf "$out/stats" "$out/pmc_wave"
+# LAST: the driver's smoke() on exactly this tree (it was red because nothing re-ran it after the last change)
+(timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; echo "smoke rc=$?" >> "$out/smoke.log") < /dev/null
+tail -n 6 "$out/smoke.log" | cut -c1-300
