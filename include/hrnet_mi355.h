@@ -129,7 +129,11 @@ int hrn_preprocess_frame(hrn_handle h, const uint8_t *frame_dev, int frame_h, in
  *   interpolation  HRN_INTER_* = the cv2.INTER_* value of the same name; anything else fails (the reference would pass it on)
  * OpenCV is not available where this library is built and tested: the arithmetic follows the published generic 8-bit path of
  * modules/imgproc/src/resize.cpp (oracle/cv2_resize_oracle.py restates it, the kernel equals that restatement bit for bit);
- * equality with a given cv2 build -- IPP / OpenCL builds differ among themselves -- is NOT pinned. */
+ * equality with a given cv2 build -- IPP / OpenCL builds differ among themselves -- is NOT pinned.  Specifically, for
+ * HRN_INTER_CUBIC this is OpenCV's SCALAR cubic path (float32 coefficients, saturate_cast<short>(c * 2048), one rounding after
+ * the vertical pass); the SIMD (AVX2 / NEON) builds shipped in the opencv-python wheels round the vertical pass differently and
+ * can differ from it by +-1 grey level per sample (nearest and linear are bit-equal).  A deployment that needs equality with ITS
+ * cv2 checks it there: tests/golden/make_cv2_golden.py produces the fixture wherever opencv-python is installed. */
 enum { HRN_INTER_NEAREST = 0, HRN_INTER_LINEAR = 1, HRN_INTER_CUBIC = 2 };
 int hrn_resize_frames(hrn_handle h, const uint8_t *frames_dev, int n, int frame_h, int frame_w, int interpolation,
                       float *images_dev, void *stream);
