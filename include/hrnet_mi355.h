@@ -225,6 +225,11 @@ int hrn_launches_per_pass(hrn_handle h);
  * created, as "NAME=value;..." -- "" in production.  They are read at hrn_create only, never during a call, and not at all
  * when HRN_IGNORE_ENV=1 is set (release mode: the library's behaviour does not depend on the caller's environment). */
 const char *hrn_switches(hrn_handle h);
+/* Debug: the number of elements at pad / guard positions of the activation workspace that are not zero (synchronises the
+ * device; -1 on error or on a plan-only handle).  The layout's invariant -- every 3x3 convolution's zero padding is the pad
+ * column / pad row shared by neighbouring rows and images, written as zeros or never touched by every kernel -- says 0 after
+ * any sequence of calls; the GPU tests check it after every path of the engine has run. */
+int64_t hrn_debug_pad_violations(hrn_handle h);
 /* Block map of the `group`-th grouped BasicBlock launch for a call of n crops, as the host would upload it (works on
  * plan-only handles: the CPU tests check that every (conv, cout tile, M tile) is covered exactly once).  Per block six
  * int32: descriptor, cout tile, M tiles walked, first M tile, pixels per M tile, flags (1 = fused BasicBlock, 2 =

@@ -591,6 +591,24 @@ int64_t hrn_map_rebuilds(hrn_handle h) { return h ? h->map_builds : -1; }
 int hrn_launches_per_pass(hrn_handle h) { return h ? (int)h->ops.size() : 0; }
 const char *hrn_switches(hrn_handle h) { return h ? h->switches.c_str() : ""; }
 
+int64_t hrn_debug_pad_violations(hrn_handle h) {
+    if (!h || h->plan_only) return -1;
+    if (!h->hip_ok(hipSetDevice(h->device), "hipSetDevice")) return -1;
+    unsigned long long *cnt = nullptr, host = 0;
+    if (!h->hip_ok(hipMalloc((void **)&cnt, sizeof *cnt), "hipMalloc") || !h->hip_ok(hipMemset(cnt, 0, sizeof *cnt), "hipMemset")) return -1;
+    bool ok = h->hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    for (const Buffer &b : h->buffers) {
+        if (!ok) break;
+        PadCheckArgs a;
+        a.buf = b.dev, a.count = cnt, a.rows = (long)b.rows, a.lead_rows = (long)b.lead_rows;
+        a.c = b.c, a.h = b.h, a.w = b.w, a.wp = b.w + 1, a.hpwp = (b.h + 1) * (b.w + 1), a.nmax = h->max_batch;
+        ok = h->hip_ok(launch_pad_check(h->dtype, a, nullptr), "pad check launch");
+    }
+    ok = ok && h->hip_ok(hipMemcpy(&host, cnt, sizeof host, hipMemcpyDeviceToHost), "hipMemcpy");
+    (void)hipFree(cnt);
+    return ok ? (int64_t)host : -1;
+}
+
 int hrn_plan_queue(hrn_handle h, int group, int n, int reverse, int32_t *units, int capacity, int32_t *info) {
     if (!h || n <= 0 || n > h->max_batch) return -1;
     if (group < 0 || group >= (int)h->groups.size()) return -1;

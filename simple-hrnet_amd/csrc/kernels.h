@@ -275,6 +275,14 @@ struct TapArgs {           // debug tap: crops crop0, crop0 + crop_step, ... of 
 };
 hipError_t launch_tap(int dtype, const TapArgs &a, hipStream_t s);
 
+struct PadCheckArgs {      // debug: one workspace buffer (guard rows + nmax images of (h + 1) x (w + 1) rows of c channels)
+    const void *buf;       // allocation start (NOT row 0 of image 0)
+    unsigned long long *count;
+    long rows, lead_rows;  // rows of the buffer, guard rows in front of image 0
+    int c, h, w, wp, hpwp, nmax;
+};
+hipError_t launch_pad_check(int dtype, const PadCheckArgs &a, hipStream_t s);
+
 hipError_t launch_conv(int dtype, const ConvArgs &a, int nr, hipStream_t s);
 // grouped launch of the generic kernel: device-resident ConvArgs[], block map entries (prob | cout tile << 8, M tile)
 hipError_t launch_conv_group(int dtype, const ConvArgs *probs_dev, const void *map_dev, int nblocks, int nr, int mr, int wlds,

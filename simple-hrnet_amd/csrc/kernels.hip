@@ -1074,6 +1074,36 @@ hipError_t launch_tap(int dtype, const TapArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Debug (hrn_debug_pad_violations): count the elements of a flat padded NHWC buffer that sit at a pad or guard position and are not
+// +0 / -0: the workspace invariant every 3x3 convolution's zero padding rests on (ctx_plan.inc: new_tensor).
+template <int DT>
+__global__ __launch_bounds__(256) void pad_check_kernel(const PadCheckArgs p) {
+    using T = Tr<DT>;
+    const typename T::elem *buf = (const typename T::elem *)p.buf;
+    unsigned long long bad = 0;
+    for (long row = (long)blockIdx.x * 256 + threadIdx.x; row < p.rows; row += (long)gridDim.x * 256) {
+        const long q = row - p.lead_rows;
+        bool pad = q < 0 || q >= (long)p.nmax * p.hpwp;                 // guard rows in front of image 0 / behind the last image
+        if (!pad) {
+            const int rem = (int)(q % p.hpwp), r = rem / p.wp, c = rem - r * p.wp;
+            pad = r >= p.h || c >= p.w;                                 // the shared pad row / pad column of an image
+        }
+        if (pad)
+            for (int ch = 0; ch < p.c; ++ch) bad += T::ld(buf[(size_t)row * p.c + ch]) != 0.f ? 1ull : 0ull;
+    }
+    if (bad) atomicAdd(p.count, bad);
+}
+
+hipError_t launch_pad_check(int dtype, const PadCheckArgs &a, hipStream_t s) {
+    if (a.rows <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((a.rows + 255) / 256 < 4096 ? (a.rows + 255) / 256 : 4096);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL(pad_check_kernel<DT_BF16>, dim3(blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(pad_check_kernel<DT_F32>, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t s) {
     const int total = a.n * a.joints;
     if (total <= 0) return hipSuccess;

@@ -392,6 +392,10 @@ class NativeHRNet:
     def launches_per_pass(self) -> int:
         return int(self._lib.hrn_launches_per_pass(self._h))
 
+    def pad_violations(self) -> int:
+        """debug: non-zero elements at pad / guard positions of the activation workspace (0 = the layout's invariant holds)"""
+        return int(self._lib.hrn_debug_pad_violations(self._h))
+
     def switches(self) -> str:
         """the HRN_* environment switches this engine saw when it was created ("" in production; HRN_IGNORE_ENV=1: always "")"""
         return self._lib.hrn_switches(self._h).decode()
