@@ -221,6 +221,10 @@ int64_t hrn_map_rebuilds(hrn_handle h);
 /* The number of entries of the static launch list (grouped launches count once).  A small call may issue more kernels: a
  * stride-2 slab group with too few tiles runs its convolutions on the generic kernel (one or more launches), a debug tap adds one. */
 int hrn_launches_per_pass(hrn_handle h);
+/* 1 when the handle runs the stem (conv1 + bn1 + ReLU + conv2 + bn2 + ReLU, models_/hrnet.py:158-163) as ONE kernel that
+ * keeps conv1's output in LDS (bf16 HRNet handles whose crop width fits; bit-identical to the two launches, which remain
+ * the path of hrn_forward_tap("stem") and of HRN_DISABLE_STEM_FUSE=1); hrn_launches_per_pass counts it as one launch. */
+int hrn_stem_fused(hrn_handle h);
 /* The HRN_* environment switches (same-box A/B runs, bit-identity tests) this handle saw when it was
  * created, as "NAME=value;..." -- "" in production.  They are read at hrn_create only, never during a call, and not at all
  * when HRN_IGNORE_ENV=1 is set (release mode: the library's behaviour does not depend on the caller's environment). */

@@ -18,7 +18,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libhrnet_mi355.so")
 if os.environ.get("HRN_LIB_TAG"):   # A/B runs of compile-time variants (tools/mkvariant.sh builds libhrnet_mi355_<tag>.so beforehand)
     LIB_PATH = LIB_PATH.replace(".so", "_%s.so" % os.environ["HRN_LIB_TAG"])
-SOURCES = ["kernels.hip", "conv3x3_lds.hip", "conv_s2.hip", "conv3x3_f32.hip", "bottleneck_chain.hip", "prepath.hip", "nms.hip", "postproc.cpp", "hrnet_mi355.cpp"]
+SOURCES = ["kernels.hip", "conv3x3_lds.hip", "conv_s2.hip", "stem_fused.hip", "conv3x3_f32.hip", "bottleneck_chain.hip", "prepath.hip", "nms.hip", "postproc.cpp", "hrnet_mi355.cpp"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv3x3_n96.inc"), os.path.join(INCLUDE, "hrnet_mi355.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-Wno-inline-asm"]
 
@@ -161,6 +161,7 @@ SYMBOLS = {
     "hrn_map_rebuilds": (ctypes.c_int64, [_P]),
     "hrn_launches_per_pass": (ctypes.c_int, [_P]),
     "hrn_switches": (ctypes.c_char_p, [_P]),
+    "hrn_stem_fused": (ctypes.c_int, [_P]),
     "hrn_debug_pad_violations": (ctypes.c_int64, [_P]),
     "hrn_plan_block_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int]),
     "hrn_plan_queue": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P]),

@@ -52,7 +52,7 @@ struct hrn_ctx {
     std::vector<Conv3Group> groups;
     std::vector<DirectGroup> dgroups;
     std::vector<S2Group> s2groups;
-    S2Problem *s2probs_dev = nullptr;
+    S2Problem *s2probs_dev = nullptr;   // (the problems of `s2groups`, then of `stemf`)
     struct Chain {
         int conv3, conv1, ds;  // conv3 of Bottleneck b, conv1 of Bottleneck b+1, projection shortcut folded in (or -1)
     };
@@ -110,6 +110,11 @@ struct hrn_ctx {
     int s2_min_tiles = env_sw("HRN_S2_MIN_TILES") ? atoi(env_sw("HRN_S2_MIN_TILES")) : 256;
     int s2_target_blocks = env_sw("HRN_S2_BLOCKS") ? std::max(1, atoi(env_sw("HRN_S2_BLOCKS"))) : 256;
     bool disable_stem_mfma = env_sw("HRN_DISABLE_STEM_MFMA") != nullptr;
+    // round 4: conv1 + conv2 of the stem as one kernel (stem_fused.hip), bit-identical to the two launches it replaces
+    bool disable_stem_fuse = env_sw("HRN_DISABLE_STEM_FUSE") != nullptr;
+    bool stem_fuse = false;       // planned (bf16 HRNet whose geometry fits: stem_fused_fits)
+    int stem_conv2_op = -1;       // ops[] index of conv2's own launch (skipped by a pass that ran the fused kernel)
+    S2Group stemf;                // the fused kernel's problem (conv2 with one output row per tile) and block maps
     bool disable_head_mfma = env_sw("HRN_DISABLE_HEAD_MFMA") != nullptr;
     bool direct_nr6 = env_sw("HRN_DIRECT_NR6") ? atoi(env_sw("HRN_DIRECT_NR6")) != 0 : true;
     int half_stages_per_block = env_sw("HRN_HALF_STAGES") ? atoi(env_sw("HRN_HALF_STAGES")) : 8;
@@ -588,7 +593,8 @@ double hrn_flops_per_crop(hrn_handle h) {
 
 int64_t hrn_workspace_bytes(hrn_handle h) { return h ? h->workspace_bytes : 0; }
 int64_t hrn_map_rebuilds(hrn_handle h) { return h ? h->map_builds : -1; }
-int hrn_launches_per_pass(hrn_handle h) { return h ? (int)h->ops.size() : 0; }
+int hrn_launches_per_pass(hrn_handle h) { return h ? (int)h->ops.size() - (h->stem_fuse ? 1 : 0) : 0; }
+int hrn_stem_fused(hrn_handle h) { return h && h->stem_fuse ? 1 : 0; }
 const char *hrn_switches(hrn_handle h) { return h ? h->switches.c_str() : ""; }
 
 int64_t hrn_debug_pad_violations(hrn_handle h) {

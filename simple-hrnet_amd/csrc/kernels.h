@@ -151,6 +151,13 @@ struct S2Problem {
 };
 hipError_t launch_conv_s2(const S2Problem *probs_dev, const void *map_dev, int nblocks, hipStream_t s);
 
+// The stem as one kernel (stem_fused.hip, round 4, bf16): conv1 computed into the stride-2 slab's LDS layout, conv2 from there;
+// one output row of conv2 per tile.  `probs_dev[.]` = conv2 as a slab-kernel problem with rows = 1 (its `in` is not read),
+// `stem` = conv1's arguments (its `out` is not written).
+constexpr int kStemFuseRegionBytes = 15360;   // one 16-channel region of a slab buffer: 480 sub-slots of 32 bytes
+constexpr int kStemFusePatchBytes = 16384;    // one patch buffer: 7 crop rows x 3 colours x (W + 8) bf16
+int stem_fused_fits(int wop, int w_in);
+
 // layer1: conv3 (+shortcut, ReLU) of one Bottleneck and conv1 (+ReLU) of the next in one pass (bottleneck_chain.hip)
 struct ChainArgs {
     const void *in;        // conv2 output of block b: [rows][64]
@@ -179,6 +186,8 @@ struct StemArgs {          // conv1 3->64 3x3 s2 + BN + ReLU, NCHW fp32 in, flat
     int out_h, out_w, out_wp, out_hpwp;
     int flip;              // read the crops mirrored left-right (flip-TTA: misc/utils.py flip_tensor(image, dim=-1))
 };
+
+hipError_t launch_stem_fused(const S2Problem *probs_dev, const void *map_dev, int nblocks, const StemArgs &stem, hipStream_t s);
 
 // Crop pre-path (prepath.hip): one person's slice of the frame, its zero padding and where its horizontal pass lives
 struct CropParams {

@@ -392,6 +392,10 @@ class NativeHRNet:
     def launches_per_pass(self) -> int:
         return int(self._lib.hrn_launches_per_pass(self._h))
 
+    def stem_fused(self) -> bool:
+        """conv1 + conv2 of the stem run as one kernel (csrc/stem_fused.hip)"""
+        return bool(self._lib.hrn_stem_fused(self._h))
+
     def pad_violations(self) -> int:
         """debug: non-zero elements at pad / guard positions of the activation workspace (0 = the layout's invariant holds)"""
         return int(self._lib.hrn_debug_pad_violations(self._h))
