@@ -155,7 +155,7 @@ hipError_t launch_conv_s2(const S2Problem *probs_dev, const void *map_dev, int n
 // one output row of conv2 per tile.  `probs_dev[.]` = conv2 as a slab-kernel problem with rows = 1 (its `in` is not read),
 // `stem` = conv1's arguments (its `out` is not written).
 constexpr int kStemFuseRegionBytes = 15360;   // one 16-channel region of a slab buffer: 480 sub-slots of 32 bytes
-constexpr int kStemFusePatchBytes = 16384;    // one patch buffer: 7 crop rows x 3 colours x (W + 8) bf16
+constexpr int kStemFusePatchBytes = 12544;    // one patch buffer: 7 crop rows x 3 colours x (W + 8) bf16 (W <= 288: the slab's limit)
 int stem_fused_fits(int wop, int w_in);
 
 // layer1: conv3 (+shortcut, ReLU) of one Bottleneck and conv1 (+ReLU) of the next in one pass (bottleneck_chain.hip)

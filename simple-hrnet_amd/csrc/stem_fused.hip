@@ -2,22 +2,30 @@
 // conv2 (64 -> 64, 3x3 stride 2, BN, ReLU; :81-83,161-163) read from there -- bf16 mode, written for gfx950.
 //
 // Separately the two convolutions write and read back the largest tensor of the pass (64 channels at half resolution: 0.9 GB
-// at 256 crops of 384x288) and took 0.43 + 0.38 ms of a 23.6-ms pass, both HBM-bound.  Here:
+// at 256 crops of 384x288) and took 0.43 + 0.38 ms of a 23.6-ms pass, both HBM-bound; this kernel takes 0.42-0.44 ms.
 //   * tile = ONE output row of conv2 of one image (R = 1 of the stride-2 slab kernel, conv_s2.hip): its input footprint is three
 //     rows of conv1's output, which need seven rows of the crop.
-//   * the crop rows come in as coalesced float4 loads, issued a whole tile before they are used (registers), are rounded to bf16 exactly as
-//     stem_mfma_kernel rounds them and kept in LDS as [row][colour][column] (the "patch").
+//   * the crop rows come in as coalesced float4 loads issued a whole tile before they are used (registers; asm, one explicit
+//     vmcnt wait per tile), are rounded to bf16 exactly as stem_mfma_kernel rounds them and kept in LDS as
+//     [row][colour][column] (the "patch").
 //   * phase A: conv1 on MFMA (K = 27 padded to one 32-wide chunk, the same weight image, bias-initialised accumulators, ReLU,
 //     bf16 rounding as stem_mfma_kernel) for the 3 x 2 x Wop slots of the stride-2 slab -- DIRECTLY in the slab's layout
 //     (de-interleaved by column parity, 32-byte sub-slots in four regions, bank pad per row pair: conv_s2.hip / kernels.h), with
 //     exact zeros where conv2's padding is.  A lane gathers its eight k-values of one conv1 pixel from the patch with
-//     ds_read_u16 (pairs packed with one v_lshl_or each).
-//   * phase B: conv2 exactly as s2_run<64, 2, 2> does it: this wave's 32 x 576 weight matrix resident in registers (144 VGPRs),
-//     no barrier in the K loop, one ds_read_b128 per two MFMAs, bias / ReLU / pad-column epilogue.
+//     ds_read_u16 (pairs packed with one v_lshl_or each), one fragment ahead of the MFMAs.
+//   * phase B: conv2 in the arithmetic of s2_run<64, 2, *>: this wave's 32 x 576 weight matrix resident in registers
+//     (144 VGPRs), no barrier in the K loop, one ds_read_b128 per two MFMAs (three chunks ahead), bias / ReLU / pad-column
+//     epilogue; one pixel fragment at a time, only the fragments the row has.
 //   * two slab buffers and two patch buffers, ONE barrier per tile.
 // Same arithmetic as the two kernels it replaces (K orders, accumulator initialisation, roundings) -> results are BIT-IDENTICAL
-// to stem_mfma_kernel + the generic / slab kernel; tests/test_stem_fused.py checks that on the whole net.  conv1's output never
-// exists in HBM (its debug tap "stem" makes the handle take the two-kernel path for that call).
+// to stem_mfma_kernel + the generic / slab kernel for finite inputs; tests/test_stem_fused.py checks that on the whole net.
+// conv1's output never exists in HBM (its debug tap "stem" makes the handle take the two-kernel path for that call).
+//
+// Where the time goes (tools/debug/stemf_timing.py on the SF_TIMING build, 256 crops of 384x288, shader clocks per tile of a
+// ~7200-clock tile): phase A ~2100-2700, patch store + next loads ~1300, phase B ~2000-2600, barrier wait ~1100.  No unit is
+// saturated (LDS pipe ~55 % busy, VALU ~35 %, MFMA ~25 %): with 144 weight VGPRs per wave the CU holds two waves per SIMD, and
+// every phase is a dependent chain (gather -> MFMA -> pack -> LDS write; LDS read -> MFMA) that two waves cannot cover.
+// profiles/EXPERIMENTS.md (round 4) has the steps that got it from 643 us to here and what each was worth.
 #include "kernels.h"
 
 namespace hrn {
@@ -28,6 +36,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define GLOBAL_AS __attribute__((address_space(1)))
+
+#ifdef SF_TIMING
+// debug build (tools/mkvariant.sh sftime SF_TIMING): shader-clock time per phase, summed over the tiles of every block, for
+// wave 0 ([0..5]) and wave 7 ([8..13]): phase A, wait for the crop rows, patch store + next loads, barrier, phase B, tiles
+__device__ unsigned long long g_sf_t[16];
+#define SF_STAMP(V) const unsigned long long V = __builtin_amdgcn_s_memtime();
+#else
+#define SF_STAMP(V)
+#endif
 
 namespace {
 
@@ -40,19 +57,11 @@ constexpr int SF_PATCH = SF_W1 + 4096;                 // two patch buffers
 constexpr int SF_LDS = SF_PATCH + 2 * kStemFusePatchBytes;
 static_assert(SF_LDS <= 160 * 1024, "LDS budget");
 
-__device__ __forceinline__ unsigned short sf_bf16(float f) {  // round to nearest even, as kernels.hip: f32_to_bf16
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-
 __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const StemArgs st, const int ntile, const int tile0, char *smem) {
-    constexpr int NF = 2, MW = 2, ROWB = 32, NCH = 18, CPP = 32, NT = 512;
+    constexpr int NF = 2, ROWB = 32, NCH = 18, CPP = 32, NT = 512;
     // everything the loop needs as scalars, once (no kernel-argument / descriptor load may be in flight while counted lgkmcnt
     // waits run: SMEM returns out of order)
     const int Ho = pp->ho, Wo = pp->wo, Wop = pp->wop, out_hpwp = pp->out_hpwp, nparts = pp->nparts;
-    const unsigned magic_wop = pp->magic_wop;
-    const int shift_wop = pp->shift_wop;
     const int H = st.H, W = st.W, flip = st.flip;
     const int h1 = st.out_h, wd1 = st.out_w;                       // conv1's output grid
     const GLOBAL_AS float *const images = (const GLOBAL_AS float *)st.images;
@@ -66,7 +75,6 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
     const int part = active ? wpart : 0;
     const int spv = 2 * Wop, PP = s2_pair_pitch(Wop);             // slots per virtual row / per row pair (with the bank pad)
     const int slots = PP + spv;                                   // three virtual rows
-    const int frags1 = (slots + 15) >> 4;                         // conv1 pixel fragments per tile
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     float *const bias_lds = (float *)(smem + SF_BIAS);
 
@@ -89,6 +97,46 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
     if (tid < 64) ((float *)(smem + SF_BIAS1))[tid] = ((const GLOBAL_AS float *)st.bias)[tid];
     const f32x4 *const b1 = (const f32x4 *)(smem + SF_BIAS1) + g * 4;   // accumulator row 4 jj + r of k-group g = channel 16 g + 4 jj + r
     for (int i = tid; i < 2 * kStemFusePatchBytes / 4; i += NT) ((unsigned *)(smem + SF_PATCH))[i] = 0u;
+    // This wave's conv1 fragments of a tile: slab slots 16 (awave + 8 i) + li, i = 0..3 (at most 30 fragments: kernels.h).  Slot ->
+    // (virtual row v, column-parity plane, j): where the window of its conv1 pixel starts in a patch (row 2 v, column index
+    // 4 j + 2 plane: see koff below), whether it is a pixel of conv1's grid at all, whether the slot exists -- the same for
+    // every tile: patch offset | v << 16 | (column inside the grid) << 18 | (slot exists) << 19
+    // Which wave takes fragments a, a + 8, ...: the waves that have ONE pixel fragment of conv2 (phase B) come first -- the
+    // conv1 fragments past a multiple of eight go to them, not to the wave of each part that has two (28 + 10 fragments over
+    // 8 waves: 5 + 5 + 5 + 5 + 5 + 5 + 4 + 4 instead of 6 + 5 + 5 + 5 + 4 + 4 + 5 + 4 -- the barrier waits for the slowest)
+    constexpr int NFA = 4;
+    int awave = 0;
+    {
+        const int mfb = (Wop + 15) >> 4;
+        int light_before = 0, heavy_before = 0, light_total = 0;
+        bool me_heavy = false;
+        for (int u = 0; u < 8; ++u) {
+            const int up = __builtin_amdgcn_readfirstlane((int)pp->wave_part[u]);
+            const int uf0 = __builtin_amdgcn_readfirstlane((int)pp->wave_f0[u]), ufs = __builtin_amdgcn_readfirstlane((int)pp->wave_fs[u]);
+            const bool heavy = up < nparts && uf0 + ufs < mfb;
+            if (u == wave) me_heavy = heavy;
+            if (u < wave) (heavy ? heavy_before : light_before) += 1;
+            if (!heavy) light_total += 1;
+        }
+        awave = me_heavy ? light_total + heavy_before : light_before;
+    }
+    const bool has_last = (awave + 8 * (NFA - 1)) * 16 < slots;      // (wave-uniform) the fourth fragment exists
+    unsigned fa[NFA];
+#pragma unroll
+    for (int i = 0; i < NFA; ++i) {
+        const int s = (awave + 8 * i) * 16 + li;
+        const int pr = s >= PP ? 1 : 0, o = s - pr * PP;
+        const int second = (pr == 0 && o >= spv) ? 1 : 0;
+        int rem = o - second * spv;
+        const bool exists = s < slots;
+        const bool in_row = rem < spv && exists;          // (not the bank pad between the row pairs, not past the end)
+        if (rem >= spv) rem = spv - 1;
+        const int v = exists ? 2 * pr + second : 0;
+        const int plane = rem >= Wop ? 1 : 0, j = exists ? rem - plane * Wop : 0;
+        const int c1 = 2 * j - 1 + plane;
+        const bool colok = in_row && c1 >= 0 && c1 < wd1;
+        fa[i] = (unsigned)((2 * v * 3 * PW + 4 * j + 2 * plane) * 2) | ((unsigned)v << 16) | (colok ? 1u << 18 : 0u) | (exists ? 1u << 19 : 0u);
+    }
     const int cout = pp->part[part].cout, ch0 = pp->part[part].ch0, relu = pp->part[part].relu;
     GLOBAL_AS unsigned short *const out = (GLOBAL_AS unsigned short *)pp->part[part].out;
     const float lo = relu ? 0.f : -INFINITY;
@@ -109,13 +157,29 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
         const int ci = 32 * sub + 8 * g;
         xoff[sub] = (ci / 16) * SF_REGION + (ci % 16) * 2;
     }
-    auto chunk_off = [&](int c) -> unsigned {   // c is a compile-time constant at every call
+    auto tap_off = [&](int c) -> unsigned {     // c is a compile-time constant at every call; the value is wave-uniform
         const int tap = c / 2, dh = tap / 3, dw = tap - 3 * dh;
-        return (unsigned)(((dh == 2 ? PP : dh * spv) + (dw & 1) * Wop + (dw >> 1)) * ROWB) + (unsigned)xoff[c % 2];
+        return (unsigned)(((dh == 2 ? PP : dh * spv) + (dw & 1) * Wop + (dw >> 1)) * ROWB);
     };
 
-    // ---- the crop rows of a tile: (row r = 0..6, colour) lines of W floats = 21 W / 4 float4s, up to three per thread
+    // ---- the crop rows of a tile: (row r = 0..6, colour) lines of W floats = 21 W / 4 float4s, up to three per thread.  Which
+    //      float4 a thread moves does not depend on the tile: its place in the crop (without the row term) and in the patch,
+    //      computed once (the integer divisions were a fifth of the kernel's time)
     const int w4 = W >> 2, nvec = 21 * w4;
+    int f_src[3];        // byte offset within the crop of the thread's float4, less its row term: ((ci H) W + 4 x4) * 4
+    unsigned f_dst[3];   // byte offset in a patch buffer | r << 20 | (nothing to store) << 31
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        int idx = tid + q * NT;
+        const bool live = idx < nvec;
+        idx = live ? idx : nvec - 1;          // (the load is unconditional: see below)
+        const int line = idx / w4, x4 = idx - line * w4;
+        const int r = line / 3, ci = line - r * 3;
+        f_src[q] = (ci * H * W + 4 * x4) * 4;
+        // column x at index x + 4; mirrored crops (flip-TTA): column x holds pixel W - 1 - x
+        const int col = flip ? W - 4 - 4 * x4 : 4 * x4;
+        f_dst[q] = (unsigned)((line * PW + col + 4) * 2) | ((unsigned)r << 20) | (live ? 0u : 0x80000000u);
+    }
     // The loads are asm: the compiler's vmcnt bookkeeping is not path-sensitive and would wait for them (and for the epilogue's
     // stores) at the top of every loop; here ONE wait per tile, just before the values are used, a whole tile after the issue.
     // An asm load's result register must not be copied before the wait (the compiler believes the asm has completed): the
@@ -125,17 +189,16 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
     auto fetch_patch = [&](int t) {
         const int n = t / Ho, ho = t - n * Ho;
         const int y0 = 4 * ho - 3;
-        const GLOBAL_AS float *img = images + (size_t)n * 3 * H * W;
+        const GLOBAL_AS char *img = (const GLOBAL_AS char *)(images + (size_t)n * 3 * H * W);   // (wave-uniform: an SGPR pair)
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            int idx = tid + q * NT;
-            idx = idx < nvec ? idx : nvec - 1;
-            const int line = idx / w4, x4 = idx - line * w4;
-            const int r = line / 3, ci = line - r * 3;
-            int y = y0 + r;
-            y = y < 0 ? 0 : (y >= H ? H - 1 : y);
-            const GLOBAL_AS float *src = img + ((size_t)ci * H + y) * W + 4 * x4;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre[q]) : "v"(src));
+            // rows above / below the crop: clamped to a valid row (zeroed at the store)
+            unsigned fd = f_dst[q];
+            asm volatile("" : "+v"(fd));     // (opaque: or the compiler keeps every field of it in a register of its own -> spills)
+            int y = y0 + (int)((fd >> 20) & 7u);
+            y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+            const int off = f_src[q] + y * (W * 4);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pre[q]) : "v"(off), "s"(img));
         }
     };
     auto fetch_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2])); };
@@ -145,18 +208,18 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
         const int y0 = 4 * ho - 3;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const int idx = tid + q * NT;
-            if (idx < nvec) {
-                const int line = idx / w4, x4 = idx - line * w4;
-                const int y = y0 + line / 3;
+            unsigned fd = f_dst[q];
+            asm volatile("" : "+v"(fd));
+            if ((int)fd >= 0) {
+                const int y = y0 + (int)((fd >> 20) & 7u);
                 const bool in = y >= 0 && y < H;
-                const unsigned short a0 = in ? sf_bf16(pre[q][0]) : 0, a1 = in ? sf_bf16(pre[q][1]) : 0, a2 = in ? sf_bf16(pre[q][2]) : 0,
-                                     a3 = in ? sf_bf16(pre[q][3]) : 0;
-                // column x at index x + 4; mirrored crops (flip-TTA): column x holds pixel W - 1 - x
-                const int col = flip ? W - 4 - 4 * x4 : 4 * x4;
-                const unsigned lo2 = flip ? ((unsigned)a3 | ((unsigned)a2 << 16)) : ((unsigned)a0 | ((unsigned)a1 << 16));
-                const unsigned hi2 = flip ? ((unsigned)a1 | ((unsigned)a0 << 16)) : ((unsigned)a2 | ((unsigned)a3 << 16));
-                *(u32x2 *)(pb + ((size_t)line * PW + col + 4) * 2) = u32x2{lo2, hi2};
+                // rounded to bf16 as stem_mfma_kernel rounds its inputs (nearest even); mirrored: the four pixels in reverse
+                const float x0 = flip ? pre[q][3] : pre[q][0], x1 = flip ? pre[q][2] : pre[q][1];
+                const float x2 = flip ? pre[q][1] : pre[q][2], x3 = flip ? pre[q][0] : pre[q][3];
+                unsigned lo2, hi2;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo2) : "v"(x0), "v"(x1));
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi2) : "v"(x2), "v"(x3));
+                *(u32x2 *)(pb + (fd & 0xfffffu)) = u32x2{in ? lo2 : 0u, in ? hi2 : 0u};
             }
         }
     };
@@ -168,55 +231,72 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
     fetch_patch(tile0 + 1 < tlast ? tile0 + 1 : tlast);   // (always issued: see above; past the run's end the last tile again, unused)
     __syncthreads();
 
+#ifdef SF_TIMING
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0};
+#endif
     for (int k = 0; k < ntile; ++k) {
         const int t = tile0 + k, b = k & 1;
         const int n = t / Ho, ho = t - n * Ho;
+        SF_STAMP(ts0)
         // ---- phase A: conv1 for the slab's slots, fragments wave, wave + 8, ...
         {
             const unsigned pbase = lds0 + SF_PATCH + b * kStemFusePatchBytes;
             char *const sl = smem + b * SF_SLAB;
-            for (int f = wave; f < frags1; f += 8) {
-                const int s = f * 16 + li;
-                // slot -> (virtual row v, plane, j); pad slots and slots past the end compute garbage that is replaced by zeros
-                const int pr = s >= PP ? 1 : 0, o = s - pr * PP;
-                const int second = (pr == 0 && o >= spv) ? 1 : 0;
-                int rem = o - second * spv;
-                const bool in_row = rem < spv && s < slots;
-                if (rem >= spv) rem = spv - 1;
-                const int v = 2 * pr + second;
-                const int plane = rem >= Wop ? 1 : 0, j = rem - plane * Wop;
-                const int r1 = 2 * ho - 1 + v, c1 = 2 * j - 1 + plane;
-                const bool ok = in_row && r1 >= 0 && r1 < h1 && c1 >= 0 && c1 < wd1;
-                const unsigned pa = pbase + (unsigned)((2 * v * 3 * PW + 4 * j + 2 * plane) * 2);
-                // (no ds_read_u16_d16 / _d16_hi pairs: with SRAM ECC on -- every MI300 / MI355 -- a d16 load rewrites the WHOLE register)
-                unsigned xe[8];
+            // conv1's weights and biases: from LDS once per tile (per fragment they were half of phase A's LDS traffic, and LDS
+            // bandwidth is what bounds phase A); not kept across phase B: its weights need the registers
+            s16x8 w1r[4];
+            f32x4 b1r[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) w1r[jj] = w1[64 * jj], b1r[jj] = b1[jj];
+            // The gather of fragment i + 1 is in flight while fragment i is multiplied, clamped and stored: straight-line code
+            // (four fragments, the ones a wave does not have are computed on slot 0's window and not stored) so that the asm
+            // loads' registers are never copied while a load is outstanding.
+            // (no ds_read_u16_d16 / _d16_hi pairs: with SRAM ECC on -- every MI300 / MI355 -- a d16 load rewrites the WHOLE register)
+            unsigned xe[8];
+            auto gather = [&](int i) {
+                unsigned fd = fa[i];
+                asm volatile("" : "+v"(fd));
+                const unsigned pa = pbase + (fd & 0xffffu);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     // k >= 27 (the last five values of k-group 3): element 0 of the patch, a zero that is never overwritten
                     const unsigned ad = koff[e] >= 0 ? pa + (unsigned)koff[e] : pbase;
                     asm volatile("ds_read_u16 %0, %1" : "=v"(xe[e]) : "v"(ad));
                 }
+            };
+            gather(0);
+#pragma unroll
+            for (int i = 0; i < NFA; ++i) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xe[0]), "+v"(xe[1]), "+v"(xe[2]), "+v"(xe[3]), "+v"(xe[4]), "+v"(xe[5]), "+v"(xe[6]), "+v"(xe[7]));
                 unsigned xw[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xw[e] = xe[2 * e] | (xe[2 * e + 1] << 16);
+                asm volatile("" : "+v"(xw[0]), "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]));   // (packed BEFORE xe is reused)
+                if (i + 1 < NFA) gather(i + 1);     // (unconditional: no control flow around an outstanding asm load)
+                if (i == NFA - 1 && !has_last) break;
+                unsigned fd = fa[i];
+                asm volatile("" : "+v"(fd));
+                const int v = (int)((fd >> 16) & 3u);
+                const bool ok = (fd & (1u << 18)) && (unsigned)(2 * ho - 1 + v) < (unsigned)h1;   // a pixel of conv1's grid (else: conv2's padding)
                 const s16x8 xf = __builtin_bit_cast(s16x8, (u32x4{xw[0], xw[1], xw[2], xw[3]}));
                 f32x4 acc[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
-                    acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1[64 * jj]), __builtin_bit_cast(bf16x8, xf), b1[jj], 0, 0, 0);
-                // ReLU, bf16, zeros where conv2's padding is; the lane owns channels 16 g .. 16 g + 15 of its pixel = its 32-byte
-                // sub-slot in region g
+                    acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1r[jj]), __builtin_bit_cast(bf16x8, xf), b1r[jj], 0, 0, 0);
+                // ReLU (clamp to [0, inf]) or, where conv2's padding is, exact zeros (clamp to [0, 0]); bf16 (nearest even, as
+                // stem_mfma_kernel); the lane owns channels 16 g .. 16 g + 15 of its pixel = its 32-byte sub-slot in region g
+                const float hi = ok ? INFINITY : 0.f;
                 unsigned pk[8];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const float a0 = ok ? fmaxf(acc[jj][2 * h], 0.f) : 0.f, a1 = ok ? fmaxf(acc[jj][2 * h + 1], 0.f) : 0.f;
-                        pk[2 * jj + h] = (unsigned)sf_bf16(a0) | ((unsigned)sf_bf16(a1) << 16);
+                        // (the builtin, not asm: the compiler has to see this first read of the MFMA results to space it)
+                        const float a0 = __builtin_amdgcn_fmed3f(acc[jj][2 * h], 0.f, hi), a1 = __builtin_amdgcn_fmed3f(acc[jj][2 * h + 1], 0.f, hi);
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[2 * jj + h]) : "v"(a0), "v"(a1));
                     }
-                if (s < slots) {
-                    char *d = sl + g * SF_REGION + s * ROWB;
+                if (fd & (1u << 19)) {
+                    char *d = sl + g * SF_REGION + ((awave + 8 * i) * 16 + li) * ROWB;
                     *(u32x4 *)d = u32x4{pk[0], pk[1], pk[2], pk[3]};
                     *(u32x4 *)(d + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
                 }
@@ -224,59 +304,56 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
         }
         // the crop rows of tile k + 1 (issued a whole tile ago) -> the other patch buffer; then those of tile k + 2 go out: in
         // flight under phase B and the next phase A
+        SF_STAMP(ts1)
         fetch_wait();
+        SF_STAMP(ts2)
         if (k + 1 < ntile) store_patch(b ^ 1, t + 1);
         fetch_patch(t + 2 < tlast ? t + 2 : tlast);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SF_STAMP(ts3)
         __builtin_amdgcn_s_barrier();               // the slab of this tile and the patch of the next one are complete
+        SF_STAMP(ts4)
 
         // ---- phase B: conv2 over the slab (s2_run<64, 2, 2> with one output row per tile)
         const int npx = Wop;
         const int mf = (npx + 15) >> 4;
         const long q0 = (long)n * out_hpwp + (long)ho * Wop;
         if (active) {
-            for (int f0 = wf0; f0 < mf; f0 += MW * wfs) {
-                int nfr = 0;
-                int tp[MW], wo[MW];
-                unsigned xa[MW];
+            // One pixel fragment (16 pixels x this wave's 32 couts) at a time, only the fragments the row has (5 at 288 columns:
+            // one wave of each part takes two): the B operand comes from LDS once per TWO MFMAs, which at four busy SIMDs is all
+            // the LDS delivers (128 B / clock) -- a fragment nobody needs would cost what a real one does.  Reads run three
+            // chunks ahead of the MFMAs (LDS latency under this load is ~200 clocks = six MFMAs).
+            for (int f = wf0; f < mf; f += wfs) {
+                const int tp = f * 16 + li;
+                const int wo = tp < npx ? tp : 0;
+                // the two per-lane bases (k-group g of the first / second half of a tap's 64 channels); opaque, or the compiler
+                // keeps xoff + tap_off(c) for all 18 chunks in registers of their own across the whole kernel (-> spills)
+                unsigned xs[2] = {lds0 + b * SF_SLAB + wo * ROWB + (unsigned)xoff[0], lds0 + b * SF_SLAB + wo * ROWB + (unsigned)xoff[1]};
+                asm volatile("" : "+v"(xs[0]), "+v"(xs[1]));
+                f32x4 acc[NF];
 #pragma unroll
-                for (int i = 0; i < MW; ++i) {
-                    if (f0 + i * wfs < mf) nfr = i + 1;
-                    int tt = (f0 + i * wfs) * 16 + li;
-                    tp[i] = tt;
-                    if (tt >= npx) tt = 0;
-                    const int rr = (int)(((unsigned long long)(unsigned)tt * magic_wop) >> shift_wop);   // (0: one row per tile)
-                    wo[i] = tt - rr * Wop;
-                    xa[i] = lds0 + b * SF_SLAB + (rr * PP + wo[i]) * ROWB;
-                }
-                f32x4 acc[MW][NF];
-#pragma unroll
-                for (int i = 0; i < MW; ++i)
-#pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                s16x8 xf[2][MW];
-#define SF_READ(SET, C)                                                                                         \
-    {                                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < MW; ++i)                                                          \
-            asm volatile("ds_read_b128 %0, %1" : "=v"(xf[SET][i]) : "v"(xa[i] + chunk_off(C)));                 \
-    }
-                SF_READ(0, 0)
+                for (int j = 0; j < NF; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s16x8 xf[4];
+#define SF_READ(C) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[(C) & 3]) : "v"(xs[(C) & 1] + tap_off(C)));
+                SF_READ(0)
+                SF_READ(1)
+                SF_READ(2)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const int cur = c & 1;
-                    if (c + 1 < NCH) {
-                        SF_READ(cur ^ 1, c + 1)
-                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(MW) : "memory");
+                    if (c + 3 < NCH) {
+                        SF_READ(c + 3)
+                        asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                    } else if (c + 3 == NCH) {
+                        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                    } else if (c + 2 == NCH) {
+                        asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
                     } else {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < NF; ++j)
-#pragma unroll
-                        for (int i = 0; i < MW; ++i)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c][j]),
-                                                                                __builtin_bit_cast(bf16x8, xf[cur][i]), acc[i][j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c][j]), __builtin_bit_cast(bf16x8, xf[c & 3]), acc[j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #undef SF_READ
@@ -285,29 +362,36 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
                 f32x4 bs[NF];
 #pragma unroll
                 for (int j = 0; j < NF; ++j) bs[j] = *(const f32x4 *)(bl + 4 * j);
+                if (tp < npx) {
+                    const float hi = wo < Wo ? INFINITY : 0.f;
+                    const float lo_i = wo < Wo ? lo : 0.f;
+                    unsigned pk2[2 * NF];
 #pragma unroll
-                for (int i = 0; i < MW; ++i) {
-                    if (i >= nfr) break;
-                    if (tp[i] < npx) {
-                        const float hi = wo[i] < Wo ? INFINITY : 0.f;
-                        const float lo_i = wo[i] < Wo ? lo : 0.f;
-                        unsigned pk2[2 * NF];
+                    for (int j = 0; j < NF; ++j)
 #pragma unroll
-                        for (int j = 0; j < NF; ++j)
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                float a0 = acc[i][j][2 * h] + bs[j][2 * h], a1 = acc[i][j][2 * h + 1] + bs[j][2 * h + 1];
-                                asm("v_med3_f32 %0, %1, %2, %3" : "=v"(a0) : "v"(a0), "v"(lo_i), "v"(hi));
-                                asm("v_med3_f32 %0, %1, %2, %3" : "=v"(a1) : "v"(a1), "v"(lo_i), "v"(hi));
-                                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk2[2 * j + h]) : "v"(a0), "v"(a1));
-                            }
-                        GLOBAL_AS unsigned short *o = out + (size_t)(q0 + tp[i]) * cout + ch0 + g * 4 * NF;
-                        *(GLOBAL_AS u32x4 *)o = u32x4{pk2[0], pk2[1], pk2[2], pk2[3]};
-                    }
+                        for (int h = 0; h < 2; ++h) {
+                            float a0 = acc[j][2 * h] + bs[j][2 * h], a1 = acc[j][2 * h + 1] + bs[j][2 * h + 1];
+                            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(a0) : "v"(a0), "v"(lo_i), "v"(hi));
+                            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(a1) : "v"(a1), "v"(lo_i), "v"(hi));
+                            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk2[2 * j + h]) : "v"(a0), "v"(a1));
+                        }
+                    GLOBAL_AS unsigned short *o = out + (size_t)(q0 + tp) * cout + ch0 + g * 4 * NF;
+                    *(GLOBAL_AS u32x4 *)o = u32x4{pk2[0], pk2[1], pk2[2], pk2[3]};
                 }
             }
         }
+#ifdef SF_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SF_STAMP(ts5)
+        tacc[0] += ts1 - ts0, tacc[1] += ts2 - ts1, tacc[2] += ts3 - ts2, tacc[3] += ts4 - ts3, tacc[4] += ts5 - ts4;
+#endif
     }
+#ifdef SF_TIMING
+    if (lane == 0 && (wave == 0 || wave == 7)) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_sf_t[(wave ? 8 : 0) + i], tacc[i]);
+        atomicAdd(&g_sf_t[(wave ? 8 : 0) + 5], (unsigned long long)ntile);
+    }
+#endif
 }
 
 }  // namespace
@@ -338,3 +422,15 @@ hipError_t launch_stem_fused(const S2Problem *probs_dev, const void *map_dev, in
 }
 
 }  // namespace hrn
+
+#ifdef SF_TIMING
+extern "C" int hrn_debug_stem_timing(unsigned long long *out16, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(hrn::g_sf_t), sizeof(hrn::g_sf_t)) != hipSuccess) return 2;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(hrn::g_sf_t), z, sizeof z) != hipSuccess) return 3;
+    }
+    return 0;
+}
+#endif
