@@ -2,7 +2,7 @@
 // conv2 (64 -> 64, 3x3 stride 2, BN, ReLU; :81-83,161-163) read from there -- bf16 mode, written for gfx950.
 //
 // Separately the two convolutions write and read back the largest tensor of the pass (64 channels at half resolution: 0.9 GB
-// at 256 crops of 384x288) and took 0.43 + 0.38 ms of a 23.6-ms pass, both HBM-bound; this kernel takes 0.42-0.44 ms.
+// at 256 crops of 384x288) and took 0.43 + 0.38 ms of a 23.6-ms pass, both HBM-bound; this kernel takes 0.34 ms.
 //   * tile = ONE output row of conv2 of one image (R = 1 of the stride-2 slab kernel, conv_s2.hip): its input footprint is three
 //     rows of conv1's output, which need seven rows of the crop.
 //   * the crop rows come in as coalesced float4 loads issued a whole tile before they are used (registers; asm, one explicit
@@ -233,6 +233,7 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
 
 #ifdef SF_TIMING
     unsigned long long tacc[5] = {0, 0, 0, 0, 0};
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int k = 0; k < ntile; ++k) {
         const int t = tile0 + k, b = k & 1;
@@ -390,6 +391,9 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
     if (lane == 0 && (wave == 0 || wave == 7)) {
         for (int i = 0; i < 5; ++i) atomicAdd(&g_sf_t[(wave ? 8 : 0) + i], tacc[i]);
         atomicAdd(&g_sf_t[(wave ? 8 : 0) + 5], (unsigned long long)ntile);
+        // the block's life in shader clocks and in 100-MHz reference ticks: their ratio is the clock the CU actually ran at
+        atomicAdd(&g_sf_t[(wave ? 8 : 0) + 6], __builtin_amdgcn_s_memtime() - clk0);
+        atomicAdd(&g_sf_t[(wave ? 8 : 0) + 7], __builtin_amdgcn_s_memrealtime() - rt0);
     }
 #endif
 }

@@ -29,5 +29,7 @@ for tag, o in (("wave 0", 0), ("wave 7", 8)):
     tiles = out[o + 5]
     tot = sum(out[o + i] for i in range(5))
     print("%s: %d tiles, %.0f clocks per tile" % (tag, tiles, tot / max(tiles, 1)))
+    if out[o + 7]:
+        print("   shader clock during the kernel: %.0f MHz (s_memtime / s_memrealtime x 100 MHz)" % (100.0 * out[o + 6] / out[o + 7]))
     for i, nm in enumerate(names):
         print("   %-26s %8.0f clocks / tile  %5.1f %%" % (nm, out[o + i] / max(tiles, 1), 100.0 * out[o + i] / max(tot, 1)))
