@@ -20,6 +20,7 @@ CSV="$(find $out/pmc_wave -name '*counter_collection.csv' | head -1)"
 python tools/pmc_mean.py "$CSV" "conv3x3_lds_kernel<48" > "$out/round${round}_pmc_wave.txt" < /dev/null
 python tools/pmc_mean.py "$CSV" "conv_s2_slab_kernel" > "$out/round${round}_pmc_s2.txt" < /dev/null
 python tools/pmc_mean.py "$CSV" "conv_direct" > "$out/round${round}_pmc_direct.txt" < /dev/null
+python tools/pmc_mean.py "$CSV" "stem_fused_kernel" > "$out/round${round}_pmc_stem.txt" < /dev/null
 cat "$out/round${round}_pmc_wave.txt" "$out/round${round}_pmc_s2.txt"
 rm -rf "$out/stats" "$out/pmc_wave"
 # LAST: the driver's smoke() on exactly this tree (it was red because nothing re-ran it after the last change)
