@@ -8,12 +8,16 @@ mkdir -p "$out"
 (timeout 1500 python -m pytest tests -m gpu -q -rP -rs > "$out/gputest.log" 2>&1; echo "rc=$?" >> "$out/gputest.log") < /dev/null
 grep -E "bf16 pin|fp32 taps|\[peaked|SKIPPED|passed|failed|rc=" "$out/gputest.log" | cut -c1-400 > "$out/round${round}_gputest_summary.txt"
 tail -n 3 "$out/round${round}_gputest_summary.txt"
+# the PMC traffic passes FIRST: bench.py reports roofline.traffic from profiles/round*_pmc_traffic.json only when that reading was
+# taken on exactly these sources (hash inside), so the reading has to exist before the bench line is measured
+timeout 500 tools/pmc_traffic.sh $round < /dev/null | cut -c1-400
+cp gpurun_out/pmc_traffic_r$round/round${round}_pmc_*.{json,csv} profiles/ 2>/dev/null
+cp gpurun_out/pmc_traffic_r$round/round${round}_pmc_*.{json,csv} "$out/" 2>/dev/null
 timeout 500 python bench.py > "$out/bench.json" 2> "$out/bench.err" < /dev/null
 python tools/abline.py bench "$out/bench.json" < /dev/null
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$R/$out/stats" -o r$round --output-format csv -- bash -c "cd $R && python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-clip --no-config1 --no-fp32-w48 --no-prepath > $R/$out/bench_under_rocprof.json 2>/dev/null" > /dev/null 2>&1 < /dev/null)
 cp "$(find $out/stats -name '*kernel_stats.csv' | head -1)" "$out/round${round}_kernel_stats.csv" 2>/dev/null
 head -n 14 "$out/round${round}_kernel_stats.csv" | cut -c1-160
-timeout 500 tools/pmc_traffic.sh $round < /dev/null | cut -c1-400
 PMC="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d "$R/$out/pmc_wave" -o w --output-format csv -- bash -c "cd $R && python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-config1 --no-fp32-w48 --no-prepath" > /dev/null 2>&1 < /dev/null)
 CSV="$(find $out/pmc_wave -name '*counter_collection.csv' | head -1)"
