@@ -207,12 +207,10 @@ __global__ __launch_bounds__(DS ? 512 : 256, DS ? 1 : 2) void bottleneck_chain_k
 
 template <bool DS>
 static hipError_t launch_chain_t(const ChainArgs &a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)bottleneck_chain_kernel<DS>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(DS));
+    static std::atomic<unsigned long long> lds_set{0};   // per device: kernels.h set_dynamic_lds
+    {
+        const hipError_t e = set_dynamic_lds((const void *)bottleneck_chain_kernel<DS>, lds_bytes(DS), lds_set);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     // persistent: 8 waves per CU re-use their staged weights over many 16-pixel fragments
     static const int blocks_env = hrn_env("HRN_CHAIN_BLOCKS") ? atoi(hrn_env("HRN_CHAIN_BLOCKS")) : 512;

@@ -207,11 +207,10 @@ template <int NRB>
 hipError_t launch_c3f(const Conv3Problem *probs_dev, const int2 *blockmap_dev, int nblocks, int nb, hipStream_t s) {
     constexpr int LDS = 2 * F_NCH * NRB * 1024 + 2 * F_SLAB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv3x3_f32_kernel<NRB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    static std::atomic<unsigned long long> lds_set{0};   // per device: kernels.h set_dynamic_lds
+    {
+        const hipError_t e = set_dynamic_lds((const void *)conv3x3_f32_kernel<NRB>, LDS, lds_set);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((conv3x3_f32_kernel<NRB>), dim3(nblocks), dim3(512), LDS, s, probs_dev, blockmap_dev, nb);
     return hipGetLastError();

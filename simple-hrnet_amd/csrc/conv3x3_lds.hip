@@ -897,12 +897,10 @@ static hipError_t launch_c3(const Conv3Problem *probs_dev, const int2 *blockmap_
     // the <48, 3> launches may carry fused BasicBlocks (bbf_run), which lay LDS out differently and use all of it
     constexpr int LDS = (KS == 48 && NRB == 3) ? (BBF_LDS > N96_LDS ? BBF_LDS : N96_LDS) : CFG::LDS;
     static_assert(LDS >= CFG::LDS, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv3x3_lds_kernel<KS, NRB>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    static std::atomic<unsigned long long> lds_set{0};   // per device: kernels.h set_dynamic_lds
+    {
+        const hipError_t e = set_dynamic_lds((const void *)conv3x3_lds_kernel<KS, NRB>, LDS, lds_set);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((conv3x3_lds_kernel<KS, NRB>), dim3(nblocks), dim3(512), LDS, s, probs_dev, blockmap_dev, nb);
     return hipGetLastError();

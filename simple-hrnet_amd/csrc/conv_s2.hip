@@ -326,12 +326,11 @@ __global__ __launch_bounds__(512) void conv_s2_slab_kernel(const S2Problem *__re
 
 hipError_t launch_conv_s2(const S2Problem *probs_dev, const void *map_dev, int nblocks, hipStream_t s) {
     if (nblocks <= 0) return hipSuccess;
-    static bool attr_set = false;
     const int lds = 2 * kS2SlabBytes + 8 * 48 * 4;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv_s2_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static std::atomic<unsigned long long> lds_set{0};   // per device: kernels.h set_dynamic_lds
+    {
+        const hipError_t e = set_dynamic_lds((const void *)conv_s2_slab_kernel, lds, lds_set);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(conv_s2_slab_kernel, dim3(nblocks), dim3(512), lds, s, probs_dev, (const int2 *)map_dev);
     return hipGetLastError();

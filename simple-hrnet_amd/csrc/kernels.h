@@ -4,10 +4,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
 namespace hrn {
+
+// Kernels that use more than 64 KiB of dynamic LDS: hipFuncAttributeMaxDynamicSharedMemorySize is a property of the function ON
+// ONE DEVICE, so it is set once per (kernel, device) -- a process-wide "done" flag left every device but the first handle's without
+// it (one process driving several GPUs: native.MultiDeviceHRNet).  `done` = one bit per device ordinal, a static of the caller.
+inline hipError_t set_dynamic_lds(const void *func, int bytes, std::atomic<unsigned long long> &done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // The HRN_* environment switches exist for same-box A/B runs and the bit-identity tests.  They are read
 // ONCE, when a handle is created (hrn_create snapshots what it saw: hrn_switches()), never during a call -- and not at all when

@@ -415,11 +415,10 @@ int stem_fused_fits(int wop, int w_in) {
 
 hipError_t launch_stem_fused(const S2Problem *probs_dev, const void *map_dev, int nblocks, const StemArgs &stem, hipStream_t s) {
     if (nblocks <= 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)stem_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS);
+    static std::atomic<unsigned long long> lds_set{0};   // per device: kernels.h set_dynamic_lds
+    {
+        const hipError_t e = set_dynamic_lds((const void *)stem_fused_kernel, SF_LDS, lds_set);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(stem_fused_kernel, dim3(nblocks), dim3(512), SF_LDS, s, probs_dev, (const int2 *)map_dev, stem);
     return hipGetLastError();
