@@ -256,7 +256,9 @@ int hrn_plan_direct_map(hrn_handle h, int group, int n, int32_t *blocks, int cap
 /* Likewise for the `group`-th launch of the stride-2 slab kernel (conv_s2.hip): per block three int32 (problem, tiles walked,
  * first tile; a tile = `rows` output rows of one image, numbered image-major); per part five int32 (problem, convolution
  * index, 48-cout tile of it, output rows per tile, tiles per image); *active = 1 when a call of n crops takes this kernel
- * (0: too few tiles, the same convolutions run on the generic kernel).  Returns blocks | (parts << 20), -1 for a bad group / n. */
+ * (0: too few tiles, the same convolutions run on the generic kernel).  Returns blocks | (parts << 20), -1 for a bad group / n.
+ * group = -1: the fused stem kernel's map (hrn_stem_fused; stem_fused.hip): conv2 with ONE output row per tile, two parts of 32
+ * couts, at most one block per CU, every block an equal run of tiles. */
 int hrn_plan_s2_map(hrn_handle h, int group, int n, int32_t *blocks, int capacity, int32_t *parts, int part_capacity,
                     int32_t *active);
 /* per-kernel HIP-event timing of one pass (dominant-kernel roofline in bench.py):

@@ -672,8 +672,10 @@ int hrn_plan_direct_map(hrn_handle h, int group, int n, int32_t *blocks, int cap
 
 int hrn_plan_s2_map(hrn_handle h, int group, int n, int32_t *blocks, int capacity, int32_t *parts, int part_capacity, int32_t *active) {
     if (!h || n <= 0 || n > h->max_batch) return -1;
-    if (group < 0 || group >= (int)h->s2groups.size()) return -1;
-    const S2Group &g = h->s2groups[group];
+    // group -1: the fused stem's problem (conv2 with one output row per tile), when the handle runs it (hrn_stem_fused)
+    if (group == -1 && !h->stem_fuse) return -1;
+    if (group < -1 || group >= (int)h->s2groups.size()) return -1;
+    const S2Group &g = group == -1 ? h->stemf : h->s2groups[group];
     std::vector<int2> map;
     const int nblocks = h->s2_blocks(g, n, &map);
     for (int i = 0; i < nblocks && i < capacity; ++i)

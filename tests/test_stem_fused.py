@@ -45,6 +45,34 @@ def test_too_wide_crops_keep_the_two_launches():
         net.close()
 
 
+def test_block_map_one_equal_run_per_cu():
+    """every (image, output row of conv2) is somebody's tile exactly once; at most 256 blocks, all runs equal but the last"""
+    import ctypes
+    pkg = load_pkg()
+    for c, hw, mb in [(48, (384, 288), 256), (32, (256, 192), 64), (48, (64, 64), 5)]:
+        net = pkg.NativeHRNet(c, 17, hw, "bf16", max_batch=mb, device=-1)
+        ho = hw[0] // 4
+        for n in sorted({1, 2, 3, mb // 2 + 1, mb}):
+            blocks = (ctypes.c_int32 * (3 * 65536))()
+            parts = (ctypes.c_int32 * (5 * 16))()
+            act = ctypes.c_int32()
+            r = net._lib.hrn_plan_s2_map(net._h, -1, n, blocks, 65536, parts, 16, ctypes.byref(act))
+            assert r >= 0
+            nb, npart = r & 0xfffff, r >> 20
+            b = np.array(blocks[:3 * nb]).reshape(-1, 3)
+            p = np.array(parts[:5 * npart]).reshape(-1, 5)
+            assert npart == 2 and (p[:, 3] == 1).all() and (p[:, 4] == ho).all() and sorted(p[:, 2]) == [0, 1]
+            cover = np.zeros(n * ho, np.int32)
+            for prob, cnt, t0 in b:
+                assert prob == 0 and cnt >= 1
+                cover[t0:t0 + cnt] += 1
+            assert (cover == 1).all(), (c, hw, n)
+            assert nb <= 256
+            runs = sorted(b[:, 1])
+            assert runs[-1] == -(-n * ho // 256) and runs[-1] - runs[0] <= max(1, runs[-1] - 1) and len(set(runs[1:])) <= 1, (n, runs[:3], runs[-3:])
+        net.close()
+
+
 GEOMS = [(48, 384, 288, 3), (48, 256, 192, 5), (32, 256, 192, 2), (48, 64, 64, 2), (48, 96, 160, 3), (32, 128, 96, 4), (48, 32, 32, 7),
          (32, 96, 288, 3), (32, 160, 224, 2), (48, 224, 32, 2)]
 
