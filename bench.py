@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-clip", action="store_true", help="skip the configs[4] clip block")
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] fp32 side line")
     ap.add_argument("--no-peaked", action="store_true", help="skip parity.peaked (bf16 px-match on the peaked checkpoint)")
+    ap.add_argument("--no-two-lanes", action="store_true", help="skip the side measurement with two engines sharing the GPU")
     ap.add_argument("--no-fp32-w48", action="store_true", help="skip the fp32 line on the headline shape")
     ap.add_argument("--clip", action="store_true", help="ONLY the configs[4] clip measurement (its JSON line is the clip block)")
     ap.add_argument("--check-gather", action="store_true", help="N > 1: compare the all-gathered joints with one engine run over every rank's crops")
@@ -837,6 +838,30 @@ def main():
                 "pass_ms": {"convs": round(sum(conv_ms), 3), **{k: round(v, 3) for k, v in other.items()}},
                 "source_hash": source_hash(),
             }
+        # Side measurement, never `value`: the same step with TWO engines on this GPU, each on its own stream with half of the
+        # batch (native.MultiDeviceHRNet; what --lanes 2 times as the main path).  The launches of one engine fill the tails and
+        # drains of the other's: same kernels, same joints, twice the activation workspace.
+        if world == 1 and lanes_eng is None and not a.no_two_lanes and a.model_name == "HRNet" and a.batch >= 4:
+            try:
+                native = importlib.import_module("simple-hrnet_amd.native")
+                two = native.MultiDeviceHRNet([local, local], a.c, 17, (a.height, a.width), a.dtype,
+                                              max_batch=min(a.max_batch, -(-a.batch // 2)), model_name=a.model_name).adopt_from(net)
+                for _ in range(2):
+                    p2 = two.predict_crops(images, boxes)
+                torch.cuda.synchronize()
+                n2 = max(3, min(a.steps, 10))
+                t2 = time.perf_counter()
+                for _ in range(n2):
+                    p2 = two.predict_crops(images, boxes)
+                torch.cuda.synchronize()
+                v2 = a.batch * n2 / (time.perf_counter() - t2)
+                out["two_lanes"] = {"crops_per_s": round(v2, 1), "vs_value": round(v2 / value, 4), "steps": n2,
+                                    "same_joints_as_one_engine": bool(torch.equal(p2, pts)),
+                                    "workspace_bytes_total": int(sum(e.workspace_bytes() for e in two.nets)),
+                                    "note": "two engines on one GPU, %d crops each per step, on two streams" % (-(-a.batch // 2))}
+                two.close()
+            except Exception as e:   # a side measurement: never lose the main one to it
+                out["two_lanes"] = {"error": "%s: %s" % (type(e).__name__, e)}
         cpu = None
         tmpdir = tempfile.mkdtemp(prefix="hrn_bench_")
         if world == 1 and not a.no_cpu_baseline and a.model_name == "HRNet":

@@ -15,11 +15,11 @@ cp gpurun_out/pmc_traffic_r$round/round${round}_pmc_*.{json,csv} profiles/ 2>/de
 cp gpurun_out/pmc_traffic_r$round/round${round}_pmc_*.{json,csv} "$out/" 2>/dev/null
 timeout 500 python bench.py > "$out/bench.json" 2> "$out/bench.err" < /dev/null
 python tools/abline.py bench "$out/bench.json" < /dev/null
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$R/$out/stats" -o r$round --output-format csv -- bash -c "cd $R && python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-clip --no-config1 --no-fp32-w48 --no-prepath > $R/$out/bench_under_rocprof.json 2>/dev/null" > /dev/null 2>&1 < /dev/null)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$R/$out/stats" -o r$round --output-format csv -- bash -c "cd $R && python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-clip --no-config1 --no-fp32-w48 --no-two-lanes --no-prepath > $R/$out/bench_under_rocprof.json 2>/dev/null" > /dev/null 2>&1 < /dev/null)
 cp "$(find $out/stats -name '*kernel_stats.csv' | head -1)" "$out/round${round}_kernel_stats.csv" 2>/dev/null
 head -n 14 "$out/round${round}_kernel_stats.csv" | cut -c1-160
 PMC="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d "$R/$out/pmc_wave" -o w --output-format csv -- bash -c "cd $R && python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-config1 --no-fp32-w48 --no-prepath" > /dev/null 2>&1 < /dev/null)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d "$R/$out/pmc_wave" -o w --output-format csv -- bash -c "cd $R && python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-clip --no-config1 --no-fp32-w48 --no-two-lanes --no-prepath" > /dev/null 2>&1 < /dev/null)
 CSV="$(find $out/pmc_wave -name '*counter_collection.csv' | head -1)"
 python tools/pmc_mean.py "$CSV" "conv3x3_lds_kernel<48" > "$out/round${round}_pmc_wave.txt" < /dev/null
 python tools/pmc_mean.py "$CSV" "conv_s2_slab_kernel" > "$out/round${round}_pmc_s2.txt" < /dev/null
