@@ -225,6 +225,11 @@ int hrn_launches_per_pass(hrn_handle h);
  * keeps conv1's output in LDS (bf16 HRNet handles whose crop width fits; bit-identical to the two launches, which remain
  * the path of hrn_forward_tap("stem") and of HRN_DISABLE_STEM_FUSE=1); hrn_launches_per_pass counts it as one launch. */
 int hrn_stem_fused(hrn_handle h);
+/* 1 when convolution `index` (hrn_get_conv_info numbering; algo 3 = the 96-cout form of the BasicBlock kernel) enumerates REAL
+ * pixels only: its M tiles are runs of h * w * n pixels in (image, row, column) order instead of runs of flat rows of the padded
+ * layout, so no matrix instruction is spent on the pad column / pad row (9 % of the 24x18 grid, 17 % of 12x9).  Same input layout,
+ * same arithmetic per output pixel: bit-identical to the flat enumeration (HRN_DISABLE_COMPACT=1). */
+int hrn_conv_compact(hrn_handle h, int index);
 /* The HRN_* environment switches (same-box A/B runs, bit-identity tests) this handle saw when it was
  * created, as "NAME=value;..." -- "" in production.  They are read at hrn_create only, never during a call, and not at all
  * when HRN_IGNORE_ENV=1 is set (release mode: the library's behaviour does not depend on the caller's environment). */

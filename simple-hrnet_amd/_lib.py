@@ -162,6 +162,7 @@ SYMBOLS = {
     "hrn_launches_per_pass": (ctypes.c_int, [_P]),
     "hrn_switches": (ctypes.c_char_p, [_P]),
     "hrn_stem_fused": (ctypes.c_int, [_P]),
+    "hrn_conv_compact": (ctypes.c_int, [_P, ctypes.c_int]),
     "hrn_debug_pad_violations": (ctypes.c_int64, [_P]),
     "hrn_plan_block_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int]),
     "hrn_plan_queue": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P]),

@@ -854,6 +854,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem 
             return;
         }
         if (p.n96) {  // 96 couts per block, 32-channel slices (conv3x3_n96.inc)
+            if (p.compact) {   // tiles of real pixels only (the host sets it for bm == 512 geometries with enough padding to pay)
+                if (bm.y >> 30)
+                    c3n_run<1, true>(p, nt, mt0, tiles, nb, smem);
+                else
+                    c3n_run<4, true>(p, nt, mt0, tiles, nb, smem);
+                return;
+            }
             if (bm.y >> 30)
                 c3n_run<1>(p, nt, mt0, tiles, nb, smem);
             else if (p.bm == 512)
@@ -912,13 +919,18 @@ hipError_t launch_conv3x3_queue(const QUnit *qunits_dev, int nunits, int *heads_
 }
 
 int conv3x3_n96_ch64() { return N96_CH64; }
+int conv3x3_n96_max_rows() { return N96_MAXROWS; }
 
 int conv3x3_lds_bbf_ok(int wp) { return (512 + 4 * (wp + 1)) * 6 <= BBF_XY / 16; }
 
 // pixels per M tile for a (KS, wp) pair: 512, or 384 when two 512-row slabs (+ halo) would not fit in LDS; 0 = unsupported
 int conv3x3_lds_bm(int ks, int nrb, int wp) {
     if (ks == 16) return conv3x3_f32_bm(wp);   // fp32 kernel
-    if (ks == 32 && nrb == 6) return 512 + 2 * wp + 2 <= N96_MAXROWS ? 512 : 384 + 2 * wp + 2 <= N96_MAXROWS ? 384 : 0;
+    // (96-cout form: the last LDS-DMA piece of a slab is written in whole 16-row chunks -- the rows, rounded up to 16, must fit the buffer)
+    if (ks == 32 && nrb == 6) {
+        auto fits = [&](int bm) { return (bm + 2 * wp + 2 + 15) / 16 * 16 <= N96_MAXROWS; };
+        return fits(512) ? 512 : fits(384) ? 384 : 0;
+    }
     const int maxrows = ks == 48 ? C3Cfg<48, 3>::MAXROWS : C3Cfg<32, 4>::MAXROWS;
     if (nrb != 4 && 512 + 2 * wp + 2 <= maxrows) return 512;
     if (384 + 2 * wp + 2 <= maxrows) return 384;

@@ -36,6 +36,7 @@ struct ConvOp {
     int64_t w_off = 0, w_bytes = 0, b_off = 0;
     // stride-2 slab kernel (conv_s2.hip): 3x3 / stride 2 / 48 input channels in bf16.  Such a convolution keeps its generic
     // plan (the small-call fallback, bit-identical) and carries a second weight image, the (48, 3) LDS form, for the slab kernel
+    bool compact = false;    // 96-cout form with the compact enumeration of M (tiles of real pixels only: conv3x3_n96.inc)
     bool s2 = false;
     bool w2_image = false;   // the slab-kernel weight image exists although the conv itself is not `s2` (conv2 under the fused stem)
     int64_t w2_off = 0, w2_bytes = 0;

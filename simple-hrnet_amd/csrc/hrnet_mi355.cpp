@@ -105,6 +105,10 @@ struct hrn_ctx {
     // EXPERIMENT (round 4): the last `tail_small` share of every 96-cout-form convolution's M tiles as 128-pixel blocks, to fill
     // the tail of a grouped launch (6.5-10 % of CU time idle: profiles/EXPERIMENTS.md) with finer work
     double tail_small = env_sw("HRN_TAIL_SMALL") ? atof(env_sw("HRN_TAIL_SMALL")) : 0.0;
+    // round 4: the 96-cout form enumerates real pixels only (no MFMAs on the pad column / pad row of the flat layout) on grids whose
+    // padding is at least this share of the flat pixels; bit-identical to the flat enumeration
+    bool disable_compact = env_sw("HRN_DISABLE_COMPACT") != nullptr;
+    double compact_min_pad = env_sw("HRN_COMPACT_MIN_PAD") ? atof(env_sw("HRN_COMPACT_MIN_PAD")) : 0.08;
     bool disable_s2 = env_sw("HRN_DISABLE_S2") != nullptr;
     // the slab kernel is taken when a launch has at least this many tiles (one per CU); smaller calls use the generic kernel
     int s2_min_tiles = env_sw("HRN_S2_MIN_TILES") ? atoi(env_sw("HRN_S2_MIN_TILES")) : 256;
@@ -595,6 +599,7 @@ int64_t hrn_workspace_bytes(hrn_handle h) { return h ? h->workspace_bytes : 0; }
 int64_t hrn_map_rebuilds(hrn_handle h) { return h ? h->map_builds : -1; }
 int hrn_launches_per_pass(hrn_handle h) { return h ? (int)h->ops.size() - (h->stem_fuse ? 1 : 0) : 0; }
 int hrn_stem_fused(hrn_handle h) { return h && h->stem_fuse ? 1 : 0; }
+int hrn_conv_compact(hrn_handle h, int index) { return h && index >= 0 && index < (int)h->convs.size() && h->convs[index].compact ? 1 : 0; }
 const char *hrn_switches(hrn_handle h) { return h ? h->switches.c_str() : ""; }
 
 int64_t hrn_debug_pad_violations(hrn_handle h) {

@@ -86,6 +86,12 @@ struct Conv3Problem {
     const float *bias2;
     // 96-cout form (conv3x3_n96.inc): KS = 32, ntiles = cout / 96, bm = 512 or 384
     int n96;
+    // ... with the COMPACT enumeration of M (round 4): tiles of real pixels only; hw = h * wd; fast divisions by hw and wd;
+    // rows of a tile's slab (the longest run of flat rows a tile of `bm` / of 128 pixels spans, + 2 wp + 2)
+    int compact, hw;
+    unsigned magic_hw, magic_w;
+    int shift_hw, shift_w;
+    int slab_rows, slab_rows_small;
 };
 // Persistent work-queue form of a grouped launch (conv3x3_queue.inc): one unit = (convolution, 96-cout tile, run of 512-pixel
 // M tiles), everything a block needs to know about it in ONE 128-byte record (fetched by LDS-DMA, 8 lanes x 16 bytes).
@@ -122,6 +128,7 @@ hipError_t launch_conv3x3_queue(const QUnit *qunits_dev, int nunits, int *heads_
                                 int bbf_blocks, int bbf_tiles, int rev, int nb, int nblocks, hipStream_t s);
 int conv3x3_n96_ch64();           // output-channel permutation of the 96-cout form's weight image (conv3x3_n96.inc)
 int conv3x3_lds_bbf_ok(int wp);  // the fused BasicBlock kernel fits this row pitch
+int conv3x3_n96_max_rows();   // rows (of 64 bytes) one slab buffer of the 96-cout form holds
 int conv3x3_lds_bm(int ks, int nrb, int wp);  // (32, 6) = the 96-cout form; ks = 16: the fp32 kernel (conv3x3_f32.hip)
 int conv3x3_f32_bm(int wp);
 hipError_t launch_conv3x3_f32(const Conv3Problem *probs_dev, const void *blockmap_dev, int nblocks, int nb, int nrb, hipStream_t s);

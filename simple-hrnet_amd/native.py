@@ -392,6 +392,10 @@ class NativeHRNet:
     def launches_per_pass(self) -> int:
         return int(self._lib.hrn_launches_per_pass(self._h))
 
+    def conv_compact(self, index: int) -> bool:
+        """convolution `index` (conv_infos numbering) runs the 96-cout form over real pixels only (csrc/conv3x3_n96.inc, CP)"""
+        return bool(self._lib.hrn_conv_compact(self._h, index))
+
     def stem_fused(self) -> bool:
         """conv1 + conv2 of the stem run as one kernel (csrc/stem_fused.hip)"""
         return bool(self._lib.hrn_stem_fused(self._h))

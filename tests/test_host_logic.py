@@ -179,7 +179,7 @@ def test_block_maps_cover_every_tile_at_other_resolutions(res, n, monkeypatch):
         for d, nt, tiles, mt0, px, flags in blocks[:nb]:
             conv = int(members[d]) & ~(1 << 30)
             i = infos[conv]
-            mtiles = -(-n * (i.out_h + 1) * (i.out_w + 1) // px)
+            mtiles = -(-n * (i.out_h * i.out_w if net.conv_compact(conv) else (i.out_h + 1) * (i.out_w + 1)) // px)
             cov = covered.setdefault((conv, int(px)), np.zeros((i.cout // (16 * i.nr), mtiles), np.int32))
             cov[nt, mt0:min(mtiles, mt0 + tiles)] += 1
             fused_blocks += int(flags & 1)
@@ -213,7 +213,7 @@ def test_block_maps_cover_every_tile_exactly_once(n, reverse):
             conv, fused = int(members[d]) & ~(1 << 30), bool(int(members[d]) >> 30)
             i = infos[conv]
             assert fused == bool(flags & 1) and (px == 512 if fused else px in (512, 384, 128)) and ((flags & 2) != 0) == (px == 128)
-            mtiles = -(-n * (i.out_h + 1) * (i.out_w + 1) // px)
+            mtiles = -(-n * (i.out_h * i.out_w if net.conv_compact(conv) else (i.out_h + 1) * (i.out_w + 1)) // px)
             assert 0 <= nt < i.cout // (16 * i.nr) and tiles >= 1 and 0 <= mt0 < mtiles
             cov = covered.setdefault((conv, fused, int(px)), np.zeros((i.cout // (16 * i.nr), mtiles), np.int32))
             cov[nt, mt0:min(mtiles, mt0 + tiles)] += 1
