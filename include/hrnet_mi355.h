@@ -231,8 +231,8 @@ int hrn_stem_fused(hrn_handle h);
  * same arithmetic per output pixel: bit-identical to the flat enumeration (HRN_DISABLE_COMPACT=1). */
 int hrn_conv_compact(hrn_handle h, int index);
 /* The HRN_* environment switches (same-box A/B runs, bit-identity tests) this handle saw when it was
- * created, as "NAME=value;..." -- "" in production.  They are read at hrn_create only, never during a call, and not at all
- * when HRN_IGNORE_ENV=1 is set (release mode: the library's behaviour does not depend on the caller's environment). */
+ * created, as "NAME=value;..." -- always "" in production: the library ignores every HRN_* variable unless the process opts in
+ * with HRN_DEBUG_ENV=1 (the test suite, tools/ab.sh).  Then they are read at hrn_create only, never during a call. */
 const char *hrn_switches(hrn_handle h);
 /* Debug: the number of elements at pad / guard positions of the activation workspace that are not zero (synchronises the
  * device; -1 on error or on a plan-only handle).  The layout's invariant -- every 3x3 convolution's zero padding is the pad
@@ -246,13 +246,6 @@ int64_t hrn_debug_pad_violations(hrn_handle h);
  * the block's conv2).  Returns the number of blocks (may exceed capacity), -1 for a bad group / n. */
 int hrn_plan_block_map(hrn_handle h, int group, int n, int reverse, int32_t *blocks, int capacity, int32_t *members,
                        int member_capacity);
-/* The persistent work-queue form (round 4) of the `group`-th grouped BasicBlock launch for a call of n crops: one block per CU
- * draws units -- (convolution, 96-cout tile, run of 512-pixel M tiles) -- from per-XCD lists; per unit four int32
- * (convolution index, cout tile, first M tile, M tiles), in queue order.  info[0..3] = the convolution whose fused
- * BasicBlock is dealt out in equal tile ranges instead of queued (-1: none), the number of blocks that take a range, its
- * 512-pixel tiles, the number of blocks of the launch.  Returns the number of units (may exceed capacity), -1 for a bad
- * group / n, -2 when the launch takes the per-block form (hrn_plan_block_map) at this n.  Works on plan-only handles. */
-int hrn_plan_queue(hrn_handle h, int group, int n, int reverse, int32_t *units, int capacity, int32_t *info);
 /* Likewise for the `group`-th grouped launch of the generic kernel: per block three int32 (descriptor, cout tile, M tile;
  * M tiles past the end are alignment padding and return at once), members[d] = convolution index, *pixels_per_tile =
  * 64 * (fragments per wave chosen for n). */

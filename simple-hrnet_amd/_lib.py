@@ -45,9 +45,25 @@ def _obj(src: str) -> str:
     return os.path.join(_obj_dir(), src.rsplit(".", 1)[0] + ".o")
 
 
+def _stamp() -> str:
+    """what the objects of this library were compiled WITH: the flags (a tagged variant adds -D flags) and the compiler's version
+    (objects built under other flags must not be reused because their sources are older)"""
+    import hashlib
+    try:
+        ver = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
+    except Exception:  # noqa: BLE001 -- no compiler: needs_build() decides whether that matters
+        ver = "?"
+    return hashlib.sha256((" ".join(HIPCC_FLAGS) + "\n" + ver).encode()).hexdigest()
+
+
+def _stamp_ok() -> bool:
+    p = os.path.join(_obj_dir(), "build.stamp")
+    return os.path.exists(p) and open(p).read().strip() == _stamp()
+
+
 def _stale(src: str) -> bool:
     o = _obj(src)
-    if not os.path.exists(o):
+    if not os.path.exists(o) or not _stamp_ok():
         return True
     t = os.path.getmtime(o)
     return any(os.path.getmtime(d) > t for d in _deps(src))
@@ -62,7 +78,13 @@ def needs_build() -> bool:
     deps = set()
     for s in SOURCES:
         deps.update(_deps(s))
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    # a library newer than its sources but built under other flags / another compiler, or whose objects are gone, is stale too --
+    # unless there is no compiler to rebuild it with (the GPU box runs the prebuilt library that travelled with the snapshot)
+    if os.path.isdir(_obj_dir()) and not _stamp_ok():
+        return shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/hipcc")
+    return False
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -92,6 +114,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                     os.replace(tmp, _obj(src))
 
                 todo = [s for s in SOURCES if force or _stale(s)]
+                stamp = _stamp()
                 with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4) or 1) as ex:
                     list(ex.map(compile_one, todo))
                 tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
@@ -99,6 +122,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 if verbose:
                     print(" ".join(cmd), flush=True)
                 subprocess.check_call(cmd)
+                with open(os.path.join(_obj_dir(), "build.stamp"), "w") as f:
+                    f.write(stamp + "\n")
                 os.replace(tmp, LIB_PATH)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
@@ -165,7 +190,6 @@ SYMBOLS = {
     "hrn_conv_compact": (ctypes.c_int, [_P, ctypes.c_int]),
     "hrn_debug_pad_violations": (ctypes.c_int64, [_P]),
     "hrn_plan_block_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int]),
-    "hrn_plan_queue": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P]),
     "hrn_plan_direct_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, _P]),
     "hrn_plan_s2_map": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, _P]),
     "hrn_profile_pass": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_int,

@@ -213,7 +213,7 @@ static hipError_t launch_chain_t(const ChainArgs &a, hipStream_t s) {
         if (e != hipSuccess) return e;
     }
     // persistent: 8 waves per CU re-use their staged weights over many 16-pixel fragments
-    static const int blocks_env = hrn_env("HRN_CHAIN_BLOCKS") ? atoi(hrn_env("HRN_CHAIN_BLOCKS")) : 512;
+    const int blocks_env = a.max_blocks > 0 ? a.max_blocks : 512;
     constexpr int WAVES = DS ? 8 : 4;
     const int mfrags = (a.m + 15) / 16;
     int blocks = (mfrags + WAVES - 1) / WAVES;

@@ -820,7 +820,6 @@ __device__ __forceinline__ void bbf_run(const Conv3Problem &p, const int mt0, co
 }
 
 #include "conv3x3_n96.inc"
-#include "conv3x3_queue.inc"
 
 template <int KS, int NRB>
 __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem *__restrict__ probs,
@@ -911,11 +910,6 @@ static hipError_t launch_c3(const Conv3Problem *probs_dev, const int2 *blockmap_
     }
     hipLaunchKernelGGL((conv3x3_lds_kernel<KS, NRB>), dim3(nblocks), dim3(512), LDS, s, probs_dev, blockmap_dev, nb);
     return hipGetLastError();
-}
-
-hipError_t launch_conv3x3_queue(const QUnit *qunits_dev, int nunits, int *heads_dev, const Conv3Problem *probs_dev, int bbf_prob,
-                                int bbf_blocks, int bbf_tiles, int rev, int nb, int nblocks, hipStream_t s) {
-    return launch_c3_queue(qunits_dev, nunits, heads_dev, probs_dev, bbf_prob, bbf_blocks, bbf_tiles, rev, nb, nblocks, s);
 }
 
 int conv3x3_n96_ch64() { return N96_CH64; }

@@ -36,15 +36,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define GLOBAL_AS __attribute__((address_space(1)))
 
-#ifdef S2_TIMING
-// debug build (tools/mkvariant.sh s2time S2_TIMING): shader clocks per block of wave 0, summed over all blocks of every launch:
-// [0] waiting for this tile's slab + the barrier, [1] the rest of the tile (K loops, epilogue, the next slab's DMA issue),
-// [2] tiles, [3] from kernel entry to the first tile (weights into registers, first slab issued), [4] blocks
-__device__ unsigned long long g_s2_t[8];
-#define S2_STAMP(V) const unsigned long long V = __builtin_amdgcn_s_memtime();
-#else
-#define S2_STAMP(V)
-#endif
 
 namespace {
 
@@ -71,9 +62,6 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
     // A slot (one input pixel, CIN * 2 bytes) lives in LDS as HALVES sub-slots of ROWB bytes in separate regions, so that the
     // 16 consecutive pixels of a fragment read are ROWB bytes apart: 96 bytes (cin = 48, 96) or 32 bytes (cin = 32, 64) -- both
     // put the eight lanes of an LDS phase on disjoint banks; 64 or 128 bytes would be 2- / 4-way conflicts.
-#ifdef S2_TIMING
-    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
-#endif
     constexpr int ROWB = s2_subslot_bytes(CIN), HALVES = CIN * 2 / ROWB, UPR = ROWB / 16;
     constexpr int NCH = (9 * CIN + 31) / 32;                         // K chunks of 32 (cin = 48: the last one half zero)
     constexpr int HALF_BYTES = s2_region_bytes(CIN);                 // LDS region of one sub-slot plane within a slab buffer
@@ -201,13 +189,8 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_s2;
 
     int nlast = 0;   // stores this wave issued AFTER its last LDS-DMA piece of the previous iteration (they may stay in flight)
-#ifdef S2_TIMING
-    unsigned long long t_wait = 0, t_work = 0;
-    const unsigned long long t_first = __builtin_amdgcn_s_memtime();
-#endif
     for (int k = 0; k < ntile; ++k) {
         const int t = tile0 + k, b = k & 1;
-        S2_STAMP(ts0)
         // my pieces of this tile's slab have landed.  vmcnt retires in order and counts stores: the youngest `nlast`
         // operations are the previous tile's last stores, everything older (all LDS-DMA pieces) must be complete
         if (nlast == 4)
@@ -220,7 +203,6 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // everybody's have; everybody is done reading the other buffer
-        S2_STAMP(ts1)
         // the next tile's slab goes out piece by piece under this tile's MFMAs (an LDS-DMA instruction costs its wave
         // ~150 issue cycles; issued in one burst by all eight waves the block would compute nothing meanwhile)
         Slab nx;
@@ -344,18 +326,7 @@ __device__ __forceinline__ void s2_run(const GLOBAL_AS S2Problem *pp, const int 
             }
         }
         for (; pk < NSP; ++pk) piece(nx, pk);   // waves without fragments in this tile (and inactive ones)
-#ifdef S2_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        S2_STAMP(ts2)
-        t_wait += ts1 - ts0, t_work += ts2 - ts1;
-#endif
     }
-#ifdef S2_TIMING
-    if (tid == 0) {
-        atomicAdd(&g_s2_t[0], t_wait), atomicAdd(&g_s2_t[1], t_work), atomicAdd(&g_s2_t[2], (unsigned long long)ntile);
-        atomicAdd(&g_s2_t[3], t_first - t_entry), atomicAdd(&g_s2_t[4], 1ull);
-    }
-#endif
 }
 
 }  // namespace
@@ -392,14 +363,3 @@ hipError_t launch_conv_s2(const S2Problem *probs_dev, const void *map_dev, int n
 
 }  // namespace hrn
 
-#ifdef S2_TIMING
-extern "C" int hrn_debug_s2_timing(unsigned long long *out8, int reset) {
-    if (hipDeviceSynchronize() != hipSuccess) return 1;
-    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(hrn::g_s2_t), sizeof(hrn::g_s2_t)) != hipSuccess) return 2;
-    if (reset) {
-        unsigned long long z[8] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(hrn::g_s2_t), z, sizeof z) != hipSuccess) return 3;
-    }
-    return 0;
-}
-#endif

@@ -55,10 +55,6 @@ struct MapSlot {
     int mr = 4;                  // generic kernel: 16-pixel fragments per wave of this map
     int2 *dev = nullptr, *pin = nullptr;
     ConvArgs *args_dev = nullptr, *args_pin = nullptr;  // generic kernel only
-    // persistent work-queue form of a grouped BasicBlock launch (conv3x3_queue.inc): unit records instead of a block map
-    QUnit *q_dev = nullptr, *q_pin = nullptr;
-    int q_units = -1;            // -1: this size takes the per-block form
-    int q_bbf_prob = 0, q_bbf_blocks = 0, q_bbf_tiles = 0;
     hipEvent_t landed = nullptr;
     hipStream_t up_stream = nullptr;   // the stream the upload went out on: a hit from ANOTHER stream waits for `landed` first
     uint64_t stamp = 0;
@@ -73,7 +69,6 @@ struct Conv3Group {
     int64_t map_capacity = 0;    // blocks at max_batch
     MapSlot slot[kMapSlots];
     std::vector<int2> map_host;  // scratch of group_blocks()
-    std::vector<QUnit> units_host;   // scratch of queue_plan()
 };
 
 // a set of independent convolutions on the generic kernel issued as ONE launch (kernels.hip: conv_direct_group_kernel)

@@ -75,6 +75,10 @@ struct hrn_ctx {
     int small_below = env_sw("HRN_SMALL_BELOW") ? atoi(env_sw("HRN_SMALL_BELOW")) : 384;
     bool disable_chain_ds = env_sw("HRN_DISABLE_CHAIN_DS") != nullptr;
     // generic conv kernel, bf16: the block's weights through LDS instead of one copy per wave from L2 (+1.6 % on the pass)
+    // residual-prefetch variant of the K = 64 1x1 convs; persistent blocks of a chain-kernel launch (read here, at create,
+    // like every other switch -- not in a function-local static at the first launch)
+    int pre_mode = env_sw("HRN_PRE_MODE") ? atoi(env_sw("HRN_PRE_MODE")) : 1;
+    int chain_blocks = env_sw("HRN_CHAIN_BLOCKS") ? atoi(env_sw("HRN_CHAIN_BLOCKS")) : 512;
     bool direct_wlds = !(env_sw("HRN_DIRECT_WLDS") && atoi(env_sw("HRN_DIRECT_WLDS")) == 0);
     // fused BasicBlocks on the 48-channel branch (conv3x3_lds.hip: bbf_run): bit-identical, 2.5x less HBM traffic on that
     // branch, +2.6 % on the whole pass at 256 crops; HRN_BBF=0 goes back to two launches per block
@@ -92,19 +96,7 @@ struct hrn_ctx {
     bool disable_f32lds = env_sw("HRN_DISABLE_F32LDS") != nullptr;   // fp32 3x3 stride-1 convs back on the generic kernel
     int f32_small_slices = env_sw("HRN_F32_SMALL_SLICES") ? atoi(env_sw("HRN_F32_SMALL_SLICES")) : 0;   // fp32: 128-pixel tiles from this many slices on (0: never; 4 and 8 measured: no gain)
     // stride-2 slab kernel (conv_s2.hip) off: those convolutions stay on the generic kernel (bit-identical results)
-    // persistent work-queue form of the grouped BasicBlock launches (round 4; bit-identical to the per-block form and, measured
-    // in the net, no faster: profiles/EXPERIMENTS.md -- so it is an option, HRN_QUEUE=1, not the default); tiles per unit; scale of
-    // the share of the CUs that start on the fused 48-channel range; fewest units per CU for a launch to take the form
-    bool queue_on = env_sw("HRN_QUEUE") && atoi(env_sw("HRN_QUEUE")) != 0;
-    int queue_tpb = env_sw("HRN_Q_TPB") ? std::max(1, atoi(env_sw("HRN_Q_TPB"))) : 1;
-    double queue_bbf_scale = env_sw("HRN_Q_BBF_SCALE") ? atof(env_sw("HRN_Q_BBF_SCALE")) : 1.2;
-    int queue_min_units_per_cu = env_sw("HRN_Q_MIN_UNITS") ? atoi(env_sw("HRN_Q_MIN_UNITS")) : 2;
-    int num_cus = 256;
-    int *qheads_dev = nullptr;   // 16 ints per grouped launch (8 used: one list head per XCD), zeroed at the start of every pass
     std::vector<Conv3Problem> probs_host;
-    // EXPERIMENT (round 4): the last `tail_small` share of every 96-cout-form convolution's M tiles as 128-pixel blocks, to fill
-    // the tail of a grouped launch (6.5-10 % of CU time idle: profiles/EXPERIMENTS.md) with finer work
-    double tail_small = env_sw("HRN_TAIL_SMALL") ? atof(env_sw("HRN_TAIL_SMALL")) : 0.0;
     // round 4: the 96-cout form enumerates real pixels only (no MFMAs on the pad column / pad row of the flat layout) on grids whose
     // padding is at least this share of the flat pixels; bit-identical to the flat enumeration
     bool disable_compact = env_sw("HRN_DISABLE_COMPACT") != nullptr;
@@ -618,21 +610,6 @@ int64_t hrn_debug_pad_violations(hrn_handle h) {
     ok = ok && h->hip_ok(hipMemcpy(&host, cnt, sizeof host, hipMemcpyDeviceToHost), "hipMemcpy");
     (void)hipFree(cnt);
     return ok ? (int64_t)host : -1;
-}
-
-int hrn_plan_queue(hrn_handle h, int group, int n, int reverse, int32_t *units, int capacity, int32_t *info) {
-    if (!h || n <= 0 || n > h->max_batch) return -1;
-    if (group < 0 || group >= (int)h->groups.size()) return -1;
-    std::vector<QUnit> u;
-    std::vector<int> uc;
-    int bbf_prob = 0, bbf_blocks = 0, bbf_tiles = 0, bbf_conv = -1;
-    if (!h->queue_plan(h->groups[group], n, reverse != 0, &u, &bbf_prob, &bbf_blocks, &bbf_tiles, &uc, &bbf_conv)) return -2;
-    for (size_t i = 0; i < u.size() && (int)i < capacity; ++i) {
-        int32_t *o = units + i * 4;
-        o[0] = uc[i], o[1] = u[i].ch_base / 96, o[2] = u[i].mt0, o[3] = u[i].ntile;
-    }
-    if (info) info[0] = bbf_conv, info[1] = bbf_blocks, info[2] = bbf_tiles, info[3] = h->num_cus;
-    return (int)u.size();
 }
 
 int hrn_plan_block_map(hrn_handle h, int group, int n, int reverse, int32_t *blocks, int capacity, int32_t *members, int member_capacity) {

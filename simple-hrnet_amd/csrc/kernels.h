@@ -24,15 +24,16 @@ inline hipError_t set_dynamic_lds(const void *func, int bytes, std::atomic<unsig
     return e;
 }
 
-// The HRN_* environment switches exist for same-box A/B runs and the bit-identity tests.  They are read
-// ONCE, when a handle is created (hrn_create snapshots what it saw: hrn_switches()), never during a call -- and not at all when
-// HRN_IGNORE_ENV=1 is set: the release mode, in which the library's behaviour does not depend on the caller's environment.
+// The HRN_* switches exist for same-box A/B runs and the bit-identity tests.  In production NONE of them is
+// read: the library's behaviour does not depend on the caller's environment.  A process that sets HRN_DEBUG_ENV=1 (the test suite,
+// tools/ab.sh) opts in; the switches are then read ONCE, when a handle is created (hrn_create snapshots what it saw:
+// hrn_switches()), never during a call.
 inline const char *hrn_env(const char *name) {
-    static const bool ignore = [] {
-        const char *v = getenv("HRN_IGNORE_ENV");
+    static const bool debug = [] {
+        const char *v = getenv("HRN_DEBUG_ENV");
         return v && *v && strcmp(v, "0") != 0;
     }();
-    return ignore ? nullptr : getenv(name);
+    return debug ? getenv(name) : nullptr;
 }
 
 enum { DT_F32 = 0, DT_BF16 = 1 };
@@ -55,6 +56,7 @@ struct ConvArgs {
     int ksize, stride, relu;
     int kchunks;                            // padded K / (32 bf16 | 16 f32)
     int rev;                                // walk the M tiles backwards (see hrn_ctx::alternate)
+    int pre_mode;                           // K = 64 1x1 convs with a residual: prefetch variant (1: residual before the K loop, 4-fragment tiles)
     int wlds;                               // bf16, full-size tiles: weights staged through LDS once per block (kernels.hip: WL)
     // one phase (a, b) of a ConvTranspose2d(4, stride 2, padding 1) run as a 3x3 conv on the input grid: the result of
     // pixel (ho, wo) is stored at (2*ho + a, 2*wo + b) of the twice-as-large tensor (poseresnet.py:84-100)
@@ -93,39 +95,6 @@ struct Conv3Problem {
     int shift_hw, shift_w;
     int slab_rows, slab_rows_small;
 };
-// Persistent work-queue form of a grouped launch (conv3x3_queue.inc): one unit = (convolution, 96-cout tile, run of 512-pixel
-// M tiles), everything a block needs to know about it in ONE 128-byte record (fetched by LDS-DMA, 8 lanes x 16 bytes).
-struct QUnit {
-    const void *in;      // row 0 of the input tensor
-    const void *w;       // packed weights of this cout tile: [slice][3 stages][18 KiB]
-    const float *bias;   // the 96 folded biases of this cout tile
-    void *out;           // row 0 of the output tensor
-    const void *res;     // row 0 of the residual tensor, or nullptr
-    int cin;             // channels per row (= cout)
-    int wp, hpwp, h, wd;
-    int relu, slices;
-    int mt0, ntile;      // first M tile, M tiles of this unit
-    int ch_base;         // first output channel of the cout tile
-    int m;               // rows of the tensors = crops * hpwp
-    unsigned magic_hpwp, magic_wp;
-    int shift_hpwp, shift_wp;
-    int pad_[7];
-};
-// the record of unit (cout tile nt, M tiles [mt0, mt0 + ntile)) of a 96-cout-form convolution for a call of nb crops
-inline QUnit make_qunit(const Conv3Problem &p, int nt, int mt0, int ntile, int nb) {
-    QUnit u{};
-    u.in = p.in, u.out = p.out, u.res = p.res;
-    u.w = (const char *)p.w + (size_t)nt * p.slices * 3 * (3 * 6 * 1024);   // [cout tile][slice][3 stages][18 KiB]
-    u.bias = p.bias + nt * 96;
-    u.cin = p.cin, u.wp = p.wp, u.hpwp = p.hpwp, u.h = p.h, u.wd = p.wd, u.relu = p.relu, u.slices = p.slices;
-    u.mt0 = mt0, u.ntile = ntile, u.ch_base = nt * 96, u.m = nb * p.hpwp;
-    u.magic_hpwp = p.magic_hpwp, u.magic_wp = p.magic_wp, u.shift_hpwp = p.shift_hpwp, u.shift_wp = p.shift_wp;
-    return u;
-}
-// blocks per launch = CUs; heads_dev: 8 zeroed ints (one list head per XCD); blocks [0, bbf_blocks) first run an equal share of
-// the bbf_tiles fused-BasicBlock tiles of descriptor probs_dev[bbf_prob]
-hipError_t launch_conv3x3_queue(const QUnit *qunits_dev, int nunits, int *heads_dev, const Conv3Problem *probs_dev, int bbf_prob,
-                                int bbf_blocks, int bbf_tiles, int rev, int nb, int nblocks, hipStream_t s);
 int conv3x3_n96_ch64();           // output-channel permutation of the 96-cout form's weight image (conv3x3_n96.inc)
 int conv3x3_lds_bbf_ok(int wp);  // the fused BasicBlock kernel fits this row pitch
 int conv3x3_n96_max_rows();   // rows (of 64 bytes) one slab buffer of the 96-cout form holds
@@ -195,6 +164,7 @@ struct ChainArgs {
     const float *bds;
     int m, h, w, wp, hpwp; // rows to produce = n*hpwp; geometry for the pad mask
     int rev;
+    int max_blocks;        // persistent blocks of the launch (512: two per CU)
 };
 hipError_t launch_bottleneck_chain(const ChainArgs &a, hipStream_t s);
 
@@ -326,6 +296,8 @@ hipError_t launch_head(int dtype, const HeadArgs &a, hipStream_t s);
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t s);
 
 // rows per block of the conv kernels: buffers keep this many guard rows after the last image
-constexpr int kConvBlockRows = 512;
+// -- and the longest slab a compact tile of the 96-cout form may read past the last image (a last tile that holds a single
+// real pixel still stages its whole slab, up to conv3x3_n96_max_rows() = 700 rows; a flat tile reads at most 512 + halo)
+constexpr int kConvBlockRows = 704;
 
 }  // namespace hrn

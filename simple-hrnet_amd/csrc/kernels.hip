@@ -321,7 +321,7 @@ static hipError_t launch_conv_tt(const ConvArgs &a, hipStream_t s) {
 template <int DT, int NR>
 static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
     if constexpr (DT == DT_BF16 && NR % 2 == 0) {
-        static const int pre_mode = hrn_env("HRN_PRE_MODE") ? atoi(hrn_env("HRN_PRE_MODE")) : 1;
+        const int pre_mode = a.pre_mode;
         if (a.res && a.ksize == 1 && pre_mode == 1) return launch_conv_tt<DT, NR, 4, true>(a, s);
         if (a.res && a.ksize == 1 && pre_mode == 2) return launch_conv_tt<DT, NR, 2, true>(a, s);
         if (a.res && a.ksize == 1 && pre_mode == 3) return launch_conv_tt<DT, NR, 2, false>(a, s);

@@ -21,7 +21,7 @@
 // to stem_mfma_kernel + the generic / slab kernel for finite inputs; tests/test_stem_fused.py checks that on the whole net.
 // conv1's output never exists in HBM (its debug tap "stem" makes the handle take the two-kernel path for that call).
 //
-// Where the time goes (tools/debug/stemf_timing.py on the SF_TIMING build, 256 crops of 384x288, shader clocks per tile of a
+// Where the time goes (per-phase shader-clock stamps of a round-4 debug build, 256 crops of 384x288, shader clocks per tile of a
 // ~7200-clock tile): phase A ~2100-2700, patch store + next loads ~1300, phase B ~2000-2600, barrier wait ~1100.  No unit is
 // saturated (LDS pipe ~55 % busy, VALU ~35 %, MFMA ~25 %): with 144 weight VGPRs per wave the CU holds two waves per SIMD, and
 // every phase is a dependent chain (gather -> MFMA -> pack -> LDS write; LDS read -> MFMA) that two waves cannot cover.
@@ -37,14 +37,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define GLOBAL_AS __attribute__((address_space(1)))
 
-#ifdef SF_TIMING
-// debug build (tools/mkvariant.sh sftime SF_TIMING): shader-clock time per phase, summed over the tiles of every block, for
-// wave 0 ([0..5]) and wave 7 ([8..13]): phase A, wait for the crop rows, patch store + next loads, barrier, phase B, tiles
-__device__ unsigned long long g_sf_t[16];
-#define SF_STAMP(V) const unsigned long long V = __builtin_amdgcn_s_memtime();
-#else
-#define SF_STAMP(V)
-#endif
 
 namespace {
 
@@ -231,14 +223,9 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
     fetch_patch(tile0 + 1 < tlast ? tile0 + 1 : tlast);   // (always issued: see above; past the run's end the last tile again, unused)
     __syncthreads();
 
-#ifdef SF_TIMING
-    unsigned long long tacc[5] = {0, 0, 0, 0, 0};
-    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
     for (int k = 0; k < ntile; ++k) {
         const int t = tile0 + k, b = k & 1;
         const int n = t / Ho, ho = t - n * Ho;
-        SF_STAMP(ts0)
         // ---- phase A: conv1 for the slab's slots, fragments wave, wave + 8, ...
         {
             const unsigned pbase = lds0 + SF_PATCH + b * kStemFusePatchBytes;
@@ -305,15 +292,11 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
         }
         // the crop rows of tile k + 1 (issued a whole tile ago) -> the other patch buffer; then those of tile k + 2 go out: in
         // flight under phase B and the next phase A
-        SF_STAMP(ts1)
         fetch_wait();
-        SF_STAMP(ts2)
         if (k + 1 < ntile) store_patch(b ^ 1, t + 1);
         fetch_patch(t + 2 < tlast ? t + 2 : tlast);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SF_STAMP(ts3)
         __builtin_amdgcn_s_barrier();               // the slab of this tile and the patch of the next one are complete
-        SF_STAMP(ts4)
 
         // ---- phase B: conv2 over the slab (s2_run<64, 2, 2> with one output row per tile)
         const int npx = Wop;
@@ -381,21 +364,7 @@ __device__ __forceinline__ void stemf_run(const GLOBAL_AS S2Problem *pp, const S
                 }
             }
         }
-#ifdef SF_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SF_STAMP(ts5)
-        tacc[0] += ts1 - ts0, tacc[1] += ts2 - ts1, tacc[2] += ts3 - ts2, tacc[3] += ts4 - ts3, tacc[4] += ts5 - ts4;
-#endif
     }
-#ifdef SF_TIMING
-    if (lane == 0 && (wave == 0 || wave == 7)) {
-        for (int i = 0; i < 5; ++i) atomicAdd(&g_sf_t[(wave ? 8 : 0) + i], tacc[i]);
-        atomicAdd(&g_sf_t[(wave ? 8 : 0) + 5], (unsigned long long)ntile);
-        // the block's life in shader clocks and in 100-MHz reference ticks: their ratio is the clock the CU actually ran at
-        atomicAdd(&g_sf_t[(wave ? 8 : 0) + 6], __builtin_amdgcn_s_memtime() - clk0);
-        atomicAdd(&g_sf_t[(wave ? 8 : 0) + 7], __builtin_amdgcn_s_memrealtime() - rt0);
-    }
-#endif
 }
 
 }  // namespace
@@ -426,14 +395,3 @@ hipError_t launch_stem_fused(const S2Problem *probs_dev, const void *map_dev, in
 
 }  // namespace hrn
 
-#ifdef SF_TIMING
-extern "C" int hrn_debug_stem_timing(unsigned long long *out16, int reset) {
-    if (hipDeviceSynchronize() != hipSuccess) return 1;
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(hrn::g_sf_t), sizeof(hrn::g_sf_t)) != hipSuccess) return 2;
-    if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(hrn::g_sf_t), z, sizeof z) != hipSuccess) return 3;
-    }
-    return 0;
-}
-#endif

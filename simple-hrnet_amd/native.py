@@ -405,7 +405,7 @@ class NativeHRNet:
         return int(self._lib.hrn_debug_pad_violations(self._h))
 
     def switches(self) -> str:
-        """the HRN_* environment switches this engine saw when it was created ("" in production; HRN_IGNORE_ENV=1: always "")"""
+        """the HRN_* environment switches this engine saw when it was created (always "" unless the process opted in with HRN_DEBUG_ENV=1)"""
         return self._lib.hrn_switches(self._h).decode()
 
     def profile_pass(self, images: torch.Tensor):

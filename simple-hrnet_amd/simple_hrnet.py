@@ -48,15 +48,22 @@ def _launcher_local_rank() -> Optional[int]:
     oversubscribe the node) -- but only when the job really has several tasks, and the rank is folded onto the
     devices this task can SEE: under ``srun --gpus-per-task=1`` / gpu-bind every task sees a single GPU at index 0 while
     SLURM_LOCALID runs 0..7."""
-    if "LOCAL_RANK" in os.environ:
-        return int(os.environ["LOCAL_RANK"])
     ndev = max(1, torch.cuda.device_count())
+    if "LOCAL_RANK" in os.environ:
+        lr = int(os.environ["LOCAL_RANK"])
+        # (ADVICE r4) torchrun does not restrict the visible devices: a local rank beyond them is a launch error, said here
+        # rather than as an invalid-device failure deep inside the engine
+        if lr < 0 or (torch.cuda.is_available() and lr >= ndev):
+            raise ValueError("LOCAL_RANK=%d but this process sees %d GPU(s): launch at most one rank per visible GPU" % (lr, ndev))
+        return lr
     for key, sizes in _LAUNCHERS:
         if key in os.environ:
-            ntasks = max([int(os.environ[k]) for k in sizes if os.environ.get(k, "").isdigit()] or [0])
-            if ntasks == 0 and os.environ.get("WORLD_SIZE", "").isdigit():
-                ntasks = int(os.environ["WORLD_SIZE"])
-            if ntasks > 1:
+            counts = [int(os.environ[k]) for k in sizes if os.environ.get(k, "").isdigit()]
+            if not counts and os.environ.get("WORLD_SIZE", "").isdigit():
+                counts = [int(os.environ["WORLD_SIZE"])]
+            # one GPU per process unless the job is EXPLICITLY a single task (ADVICE r4: a launcher that exports a local rank
+            # but no task count used to fall through and let every task build engines on all visible GPUs)
+            if not counts or max(counts) > 1:
                 return int(os.environ[key]) % ndev
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ:   # a launcher without a local-rank variable
         return int(os.environ["RANK"]) % ndev

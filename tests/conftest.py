@@ -11,6 +11,9 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The library ignores every HRN_* switch unless the process opts in (kernels.h: hrn_env); the bit-identity tests flip them.
+os.environ["HRN_DEBUG_ENV"] = "1"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -48,8 +48,24 @@ def test_srun_with_one_gpu_per_task_and_single_task_jobs(monkeypatch):
     monkeypatch.setenv("SLURM_NTASKS", "1")                         # single task: not launcher-managed
     monkeypatch.setenv("SLURM_LOCALID", "0")
     assert sh.resolve_devices("cuda") == list(range(8))
-    monkeypatch.delenv("SLURM_NTASKS")                              # no task count at all: not enough to claim a launcher
-    assert sh.resolve_devices("cuda") == list(range(8))
+    monkeypatch.delenv("SLURM_NTASKS")                              # a local rank but no task count at all: still one GPU
+    monkeypatch.setenv("SLURM_LOCALID", "5")                        # per process -- only an EXPLICIT count of 1 makes it a plain process
+    assert sh.resolve_devices("cuda") == [5]
+
+
+def test_local_rank_beyond_the_visible_gpus_is_a_launch_error(monkeypatch):
+    """torchrun's LOCAL_RANK is taken as it is (it does not restrict the visible devices), so a rank without a GPU of
+    its own is refused with a message that names the cause."""
+    sh = load_pkg("simple_hrnet")
+    for k in _LAUNCH_VARS:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert sh.resolve_devices("cuda") == [1]
+    monkeypatch.setenv("LOCAL_RANK", "2")
+    with pytest.raises(ValueError, match="LOCAL_RANK=2"):
+        sh.resolve_devices("cuda")
 
 
 def test_rank_and_world_size_without_a_local_rank(monkeypatch):
@@ -154,14 +170,14 @@ def test_nms_restores_the_callers_device_and_releases_scratch():
 
 
 def test_release_mode_ignores_the_environment_and_handles_snapshot_their_switches():
-    """the HRN_* switches are read once per handle (hrn_switches says which it saw) and not at all under
-    HRN_IGNORE_ENV=1 -- checked in fresh processes, the flag being read once per process."""
+    """production ignores every HRN_* switch; a process that sets HRN_DEBUG_ENV=1 opts in and its
+    handles snapshot what they saw (hrn_switches) -- checked in fresh processes, the flag being read once per process."""
     import subprocess, sys
     code = ("import importlib, sys; sys.path.insert(0, %r); pkg = importlib.import_module('simple-hrnet_amd');"
             "net = pkg.NativeHRNet(48, 17, (384, 288), 'bf16', max_batch=256, device=-1);"
             "print(repr(net.switches()), sum(i.algo == 3 for i in net.conv_infos()))" % ROOT)
     outs = []
-    for env in ({"HRN_DISABLE_N96": "1"}, {"HRN_DISABLE_N96": "1", "HRN_IGNORE_ENV": "1"}, {}):
+    for env in ({"HRN_DISABLE_N96": "1", "HRN_DEBUG_ENV": "1"}, {"HRN_DISABLE_N96": "1"}, {}):
         e = {k: v for k, v in os.environ.items() if not k.startswith("HRN_")}
         e.update(env)
         outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120).stdout.strip())

@@ -2,6 +2,7 @@
 # same-box sweep of creation-time switches with the shipped library: one bench line per setting
 # usage: tools/envsweep.sh <outdir> "VAR=1 VAR2=3" "VAR=2" ...      ("" = defaults)
 out=$1; shift
+export HRN_DEBUG_ENV=1   # the library ignores HRN_* switches unless the process opts in
 mkdir -p "$out"
 i=0
 for setting in "$@"; do
