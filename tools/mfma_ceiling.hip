@@ -1,0 +1,191 @@
+// VERDICT r4 item 1 -- what does the matrix pipe of this part sustain, and how far below it is the stage loop of the 96-cout form?
+//
+// Four streams, all with the graded kernel's occupancy (one 512-thread block per CU = two waves per SIMD, 96 in-place accumulators
+// per wave, v_mfma_f32_16x16x32_bf16), each run on RANDOM bf16 operands and on ZEROS (the chip clocks to its power budget:
+// MI355X_MICROARCH.md "DVFS give-back"; cdna_hip_programming.md rule 25):
+//   P  the known-good stream: NOTHING but MFMAs (operands stay in registers) -- what the pipe sustains at this occupancy
+//   L  the stage loop of csrc/conv3x3_n96.inc instruction for instruction (72 MFMAs, 18 weight + 12 pixel ds_read_b128 in the
+//      shipped interleave and with the shipped counted waits, operands from the kernel's LDS image), no barrier
+//   B  L + the stage barrier (a new slab's pixel fragments read behind it every third stage, as in the kernel)
+//   D  B + six LDS-DMA pieces per wave and stage (weights ring + slab from an L2-resident buffer), counted vmcnt before the barrier
+// For every stream: wall TFLOP/s of issued MFMAs, shader clocks per stage (s_memtime) and the clock the CUs ran at (s_memtime
+// against the 100-MHz s_memrealtime).  The kernel IN THE NET runs a stage in 3257 (cin 384) ... 3656 (cin 96) shader clocks at
+// 2.28 GHz (profiles/round2_n96_phase_timing.txt, round4_pmc_wave.txt): compare with B / D here and both with P.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_ceiling mfma_ceiling.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define GLOBAL_AS __attribute__((address_space(1)))
+constexpr int WST = 3 * 6 * 1024, SLAB = 44800, SB = 4 * WST, LDSB = SB + 2 * SLAB;
+constexpr int WP = 37;   // the 48x36 grid
+
+template <int V>
+__global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *stamps, int stages, const unsigned *init, const char *src) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    for (int i = tid; i < LDSB / 4; i += 512) ((unsigned *)smem)[i] = init[i];
+    __syncthreads();
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    f32x4 acc[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s16x8 wf[6], xf[2][4];
+    // the kernel's addresses: weights lane-linear 1-KiB fragments, pixels 64-byte rows with the XOR swizzle of conv3x3_n96.inc
+    unsigned swz = 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) swz |= (unsigned)(((wave * 64 + li + (c / 3) * WP + (c % 3)) >> 2) & 1) << c;
+    const unsigned xrow0 = lds0 + SB + (wave * 64 + li) * 64 + g * 16;
+    const int swz_step = (g & 2) ? -32 : 32;
+#define XOFF(C) ((unsigned)((((C) / 3) * WP + ((C) % 3)) * 64) + (((swz >> (C)) & 1u) ? swz_step : 0))
+#pragma unroll
+    for (int j = 0; j < 6; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j]) : "v"(lds0 + lane * 16), "i"(j * 1024));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[0][i]) : "v"(xrow0 + XOFF(0)), "i"(i * 1024));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[1][i]) : "v"(xrow0 + XOFF(1)), "i"(i * 1024));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const GLOBAL_AS char *gsrc = (const GLOBAL_AS char *)src + (size_t)(blockIdx.x & 63) * 65536 + wave * 1024;
+    const unsigned lane16 = lane * 16;
+    int q = 0, slab_par = 0;
+    for (int s = 0; s < stages / 3; ++s) {
+#pragma unroll
+      for (int P = 0; P < 3; ++P) {
+        if constexpr (V == 0) {
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[j]), "v"(xf[cc & 1][i]));
+        } else {
+            // (the kernel's counted wait: what this wave issued during the stage just finished may stay in flight, everything older has landed)
+            if constexpr (V == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if constexpr (V >= 2) __builtin_amdgcn_s_barrier();
+            const unsigned sl_a = xrow0 + slab_par * SLAB;
+            if (P == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[0][i]) : "v"(sl_a + XOFF(0)), "i"(i * 1024));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            const unsigned wl_cur = lds0 + (q & 3) * WST + lane * 16, wl_nxt = lds0 + ((q + 1) & 3) * WST + lane * 16;
+            const unsigned wdst = lds0 + ((q + 3) & 3) * WST + wave * 1024, sdst = lds0 + SB + (slab_par ^ 1) * SLAB + wave * 1024;
+            __builtin_amdgcn_sched_barrier(0);
+            {
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const int xs = (3 * P + cc) & 1;
+                    const bool xpre = !(P == 2 && cc == 2), prev_xpre = !(P == 0 && cc == 0);
+                    const unsigned wl_rd = cc == 2 ? wl_nxt : wl_cur;
+                    const unsigned xa_n = sl_a + XOFF((3 * P + cc + 1) % 9);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        if (j == 0) {
+                            if (prev_xpre) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                        } else if (j == 2) {
+                            if (xpre) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                            else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[j]), "v"(xf[xs][i]));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j]) : "v"(wl_rd), "i"((((cc + 1) % 3) * 6 + j) * 1024));
+                        if (xpre)
+#pragma unroll
+                            for (int i = j * 2; i < j * 2 + 2 && i < 4; ++i)
+                                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[xs ^ 1][i]) : "v"(xa_n), "i"(i * 1024));
+                        if constexpr (V == 3) {
+                            const int gi = cc * 6 + j, sl = gi / 3;
+                            if (gi % 3 == 1) {   // six slots: three weight pieces, three slab pieces
+                                const unsigned dst = sl < 3 ? wdst + sl * 8192 : sdst + (sl - 3) * 8192;
+                                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane16), "s"(dst), "s"(gsrc + sl * 8192) : "memory", "m0");
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ++q;
+            if (P == 2) slab_par ^= 1;
+        }
+      }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) stamps[blockIdx.x * 2] = t1 - t0, stamps[blockIdx.x * 2 + 1] = r1 - r0;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 12345.678f) out[blockIdx.x * 512 + tid] = sum;
+}
+
+static unsigned *g_init[2];
+static char *g_src[2];
+template <int V>
+static void run(const char *name, int fill) {
+    float *d; hipMalloc(&d, 256 * 512 * 4);
+    long long *st; hipMalloc(&st, 256 * 16);
+    hipFuncSetAttribute((const void *)stream_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    const int stages = 9000, blocks = 256;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    stream_kernel<V><<<blocks, 512, LDSB>>>(d, st, 60, g_init[fill], g_src[fill]);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    double ticks = 0, mhz = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        stream_kernel<V><<<blocks, 512, LDSB>>>(d, st, stages, g_init[fill], g_src[fill]);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) {
+            best = ms;
+            std::vector<long long> h(512);
+            hipMemcpy(h.data(), st, 4096, hipMemcpyDeviceToHost);
+            double a = 0, b = 0;
+            for (int i = 0; i < 256; ++i) a += h[2 * i], b += h[2 * i + 1];
+            ticks = a / 256 / stages, mhz = a / b * 100.0;
+        }
+    }
+    const double flop = (double)blocks * 8 * stages * 72.0 * 16384.0;
+    const double tf = flop / (best * 1e-3) / 1e12;
+    printf("%-58s %-6s %8.3f ms %7.1f TF issued = %4.1f %% of 2.5 PF | %6.0f clocks per stage (2304 = the pipe's 16 per MFMA) = %4.1f %% | clock %4.0f MHz\n", name,
+           fill ? "zeros" : "random", best, tf, 100 * tf / 2500, ticks, 100 * 2304.0 / ticks, mhz);
+    hipFree(d); hipFree(st);
+}
+
+int main() {
+    std::vector<unsigned> h(LDSB / 4), z(LDSB / 4, 0u);
+    srand(1);
+    for (auto &x : h) {   // two random bf16 in [-2, 2): sign, exponent 125..128, random mantissa
+        auto r = []() { unsigned s = rand() & 1, e = 125 + (rand() & 3), m = rand() & 127; return (s << 15) | (e << 7) | m; };
+        x = r() | (r() << 16);
+    }
+    hipMalloc(&g_init[0], LDSB); hipMemcpy(g_init[0], h.data(), LDSB, hipMemcpyHostToDevice);
+    hipMalloc(&g_init[1], LDSB); hipMemcpy(g_init[1], z.data(), LDSB, hipMemcpyHostToDevice);
+    for (int f = 0; f < 2; ++f) {   // what the LDS-DMA of stream D brings in: 4 MB (L2 / Infinity-Cache resident) of the same fill
+        hipMalloc(&g_src[f], 64 * 65536);
+        for (int k = 0; k < 64 * 65536 / LDSB + 1; ++k) {
+            const size_t off = (size_t)k * LDSB, n = off + LDSB <= 64 * 65536 ? LDSB : 64 * 65536 - off;
+            hipMemcpy(g_src[f] + off, f ? (const void *)z.data() : (const void *)h.data(), n, hipMemcpyHostToDevice);
+        }
+    }
+    for (int rep = 0; rep < 2; ++rep)
+        for (int fill = 0; fill < 2; ++fill) {
+            run<0>("P  MFMAs only (the known-good stream)", fill);
+            run<1>("L  stage loop of conv3x3_n96.inc, no barrier", fill);
+            run<2>("B  L + stage barrier", fill);
+            run<3>("D  B + 6 LDS-DMA pieces per wave and stage", fill);
+        }
+    return 0;
+}
