@@ -8,6 +8,9 @@
 //      shipped interleave and with the shipped counted waits, operands from the kernel's LDS image), no barrier
 //   B  L + the stage barrier (a new slab's pixel fragments read behind it every third stage, as in the kernel)
 //   D  B + six LDS-DMA pieces per wave and stage (weights ring + slab from an L2-resident buffer), counted vmcnt before the barrier
+//   H  D with the three slab pieces streamed from HBM (a 2-GB region, every block its own 8 MB; the weights stay L2-hot, as in the net)
+//   T  H + what a 96-channel tile adds every nine stages: 12 residual loads (one per slot over two stages), the epilogue's VALU work
+//      on the 96 accumulators (add, med3, pack), 12 parked stores (one per slot under the next tile's first stage), all to / from HBM
 // For every stream: wall TFLOP/s of issued MFMAs, shader clocks per stage (s_memtime) and the clock the CUs ran at (s_memtime
 // against the 100-MHz s_memrealtime).  The kernel IN THE NET runs a stage in 3257 (cin 384) ... 3656 (cin 96) shader clocks at
 // 2.28 GHz (profiles/round2_n96_phase_timing.txt, round4_pmc_wave.txt): compare with B / D here and both with P.
@@ -23,7 +26,7 @@ constexpr int WST = 3 * 6 * 1024, SLAB = 44800, SB = 4 * WST, LDSB = SB + 2 * SL
 constexpr int WP = 37;   // the 48x36 grid
 
 template <int V>
-__global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *stamps, int stages, const unsigned *init, const char *src) {
+__global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *stamps, int stages, const unsigned *init, const char *src, char *big) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
@@ -56,7 +59,16 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
     const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     const GLOBAL_AS char *gsrc = (const GLOBAL_AS char *)src + (size_t)(blockIdx.x & 63) * 65536 + wave * 1024;
     const unsigned lane16 = lane * 16;
-    int q = 0, slab_par = 0;
+    // H / T: this block's 8-MB window of the big region (slab pieces, residual tile, stores)
+    GLOBAL_AS char *const bigb = (GLOBAL_AS char *)big + (size_t)blockIdx.x * (8u << 20);
+    unsigned bpos = wave * 1024;   // running byte offset inside the window (wraps at 8 MB - 64 KB)
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 rpre[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) rpre[i][v] = u32x4{0u, 0u, 0u, 0u};
+    int q = 0, slab_par = 0, stage_in_tile = 0;
     for (int s = 0; s < stages / 3; ++s) {
 #pragma unroll
       for (int P = 0; P < 3; ++P) {
@@ -70,7 +82,13 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
                         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[j]), "v"(xf[cc & 1][i]));
         } else {
             // (the kernel's counted wait: what this wave issued during the stage just finished may stay in flight, everything older has landed)
-            if constexpr (V == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if constexpr (V >= 3) {
+                // (T: the residual loads / parked stores of the stage just finished may stay in flight too)
+                // (entering stage 7 / 8: the 6 residual loads of the stage before; entering stage 1: the 12 parked stores of stage 0)
+                if (V == 5 && (stage_in_tile == 7 || stage_in_tile == 8)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (V == 5 && stage_in_tile == 1 && s > 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            }
             if constexpr (V >= 2) __builtin_amdgcn_s_barrier();
             const unsigned sl_a = xrow0 + slab_par * SLAB;
             if (P == 0) {
@@ -104,11 +122,22 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
 #pragma unroll
                             for (int i = j * 2; i < j * 2 + 2 && i < 4; ++i)
                                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[xs ^ 1][i]) : "v"(xa_n), "i"(i * 1024));
-                        if constexpr (V == 3) {
+                        if constexpr (V >= 3) {
                             const int gi = cc * 6 + j, sl = gi / 3;
                             if (gi % 3 == 1) {   // six slots: three weight pieces, three slab pieces
                                 const unsigned dst = sl < 3 ? wdst + sl * 8192 : sdst + (sl - 3) * 8192;
-                                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane16), "s"(dst), "s"(gsrc + sl * 8192) : "memory", "m0");
+                                const GLOBAL_AS char *sp = gsrc + sl * 8192;
+                                if (V >= 4 && sl >= 3) sp = bigb + bpos + (sl - 3) * 8192;
+                                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane16), "s"(dst), "s"(sp) : "memory", "m0");
+                            } else if (V == 5) {
+                                const int idx = (gi % 3 == 2 ? 6 : 0) + sl;   // 12 slots per stage besides the DMA ones
+                                if (stage_in_tile == 6 && gi % 3 == 2) {   // residual loads: 6 per stage over the two stages before the last
+                                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rpre[sl / 3][sl % 3]) : "v"(lane16 + (unsigned)sl * 1024u), "s"(bigb + bpos + 32768) : "memory");
+                                } else if (stage_in_tile == 7 && gi % 3 == 2) {
+                                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rpre[(6 + sl) / 3][(6 + sl) % 3]) : "v"(lane16 + (unsigned)(6 + sl) * 1024u), "s"(bigb + bpos + 32768) : "memory");
+                                } else if (stage_in_tile == 0 && s > 0) {                           // the previous tile's parked stores, one per slot
+                                    *(GLOBAL_AS u32x4 *)(bigb + bpos + 49152 + idx * 1024 + lane16) = rpre[idx / 3][idx % 3];
+                                }
                             }
                         }
                     }
@@ -117,6 +146,38 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
             __builtin_amdgcn_sched_barrier(0);
             ++q;
             if (P == 2) slab_par ^= 1;
+            if constexpr (V >= 4) {
+                bpos += 3 * 8192;
+                if (bpos > (8u << 20) - 131072u) bpos = wave * 1024;
+            }
+            if constexpr (V == 5) {
+                if (++stage_in_tile == 9) {   // tile end: the epilogue (residual add, ReLU / pad mask, pack), results parked in rpre
+                    stage_in_tile = 0;
+                    asm volatile("s_nop 7\n\ts_nop 7\n\ts_waitcnt vmcnt(6)" ::: "memory");   // (the residual tile has landed; this stage's six pieces may stay in flight)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        unsigned pk[12];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            const unsigned r01 = rpre[i][j >> 1][2 * (j & 1)], r23 = rpre[i][j >> 1][2 * (j & 1) + 1];
+                            float v0 = acc[i][j][0] + __uint_as_float(r01 << 16), v1 = acc[i][j][1] + __uint_as_float(r01 & 0xffff0000u);
+                            float v2 = acc[i][j][2] + __uint_as_float(r23 << 16), v3 = acc[i][j][3] + __uint_as_float(r23 & 0xffff0000u);
+                            const float lim = __builtin_inff();
+                            asm("v_med3_f32 %0, %1, 0, %2" : "=v"(v0) : "v"(v0), "v"(lim));
+                            asm("v_med3_f32 %0, %1, 0, %2" : "=v"(v1) : "v"(v1), "v"(lim));
+                            asm("v_med3_f32 %0, %1, 0, %2" : "=v"(v2) : "v"(v2), "v"(lim));
+                            asm("v_med3_f32 %0, %1, 0, %2" : "=v"(v3) : "v"(v3), "v"(lim));
+                            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[2 * j]) : "v"(v0), "v"(v1));
+                            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[2 * j + 1]) : "v"(v2), "v"(v3));
+                        }
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) rpre[i][v] = u32x4{pk[4 * v], pk[4 * v + 1], pk[4 * v + 2], pk[4 * v + 3]};
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
         }
       }
     }
@@ -132,6 +193,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
 
 static unsigned *g_init[2];
 static char *g_src[2];
+static char *g_big;
 template <int V>
 static void run(const char *name, int fill) {
     float *d; hipMalloc(&d, 256 * 512 * 4);
@@ -139,13 +201,13 @@ static void run(const char *name, int fill) {
     hipFuncSetAttribute((const void *)stream_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     const int stages = 9000, blocks = 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    stream_kernel<V><<<blocks, 512, LDSB>>>(d, st, 60, g_init[fill], g_src[fill]);
+    stream_kernel<V><<<blocks, 512, LDSB>>>(d, st, 60, g_init[fill], g_src[fill], g_big);
     hipDeviceSynchronize();
     float best = 1e30f;
     double ticks = 0, mhz = 0;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        stream_kernel<V><<<blocks, 512, LDSB>>>(d, st, stages, g_init[fill], g_src[fill]);
+        stream_kernel<V><<<blocks, 512, LDSB>>>(d, st, stages, g_init[fill], g_src[fill], g_big);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) {
@@ -180,12 +242,16 @@ int main() {
             hipMemcpy(g_src[f] + off, f ? (const void *)z.data() : (const void *)h.data(), n, hipMemcpyHostToDevice);
         }
     }
+    hipMalloc(&g_big, (size_t)256 * (8u << 20));
+    hipMemset(g_big, 0x3c, (size_t)256 * (8u << 20));
     for (int rep = 0; rep < 2; ++rep)
         for (int fill = 0; fill < 2; ++fill) {
             run<0>("P  MFMAs only (the known-good stream)", fill);
             run<1>("L  stage loop of conv3x3_n96.inc, no barrier", fill);
             run<2>("B  L + stage barrier", fill);
             run<3>("D  B + 6 LDS-DMA pieces per wave and stage", fill);
+            run<4>("H  D, slab pieces streamed from HBM", fill);
+            run<5>("T  H + residual loads, epilogue, parked stores every 9 stages", fill);
         }
     return 0;
 }
