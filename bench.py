@@ -58,8 +58,6 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("HRN_MAX_BATCH", "256")),
                     help="crops per internal pass (workspace size)")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("HRN_LANES", "1")),
-                    help="engines per GPU, each running batch/lanes crops per step on its own stream (1 = one engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline AND parity (both need the CPU oracle)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--no-roofline", action="store_true")
@@ -705,7 +703,16 @@ def main():
 
     if a.clip:   # only the configs[4] measurement
         cpu = None
-        res, _ = clip_measure(pkg, net, dist, rank, world, cpu)
+        res, (clip, dets, mine_pts) = clip_measure(pkg, net, dist, rank, world, cpu)
+        if a.check_gather and dist:
+            # every rank holds the joints of ITS frames (zeros elsewhere): their sum over the ranks is the whole clip, which must equal
+            # what ONE engine computes when it is dealt every frame (frames are independent; the sharding must not change a joint)
+            t = torch.from_numpy(mine_pts).to(dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            alone, _ = run_clip(net, torch.from_numpy(clip).pin_memory(), dets, "per_frame", 0, 1)
+            same = bool(np.array_equal(t.cpu().numpy(), alone))
+            res["gathered_joints_equal_single_engine"] = reduce_max(0.0 if same else 1.0) == 0.0
+            res["collective_backend"] = dist.get_backend()
         if dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -719,23 +726,11 @@ def main():
     boxes_np = pkg.synth_boxes(a.batch, seed=100 + rank)
     boxes = torch.from_numpy(boxes_np).to(dev)
 
-    # the timed path: `lanes` engines on this rank's GPU, each on its own stream with batch / lanes crops per step -- the
-    # launches of one lane fill the drain and the tail of the other's (same kernels, same joints; native.MultiDeviceHRNet)
-    lanes_eng = None
-    if a.lanes > 1 and a.batch >= 2 * a.lanes:
-        native = importlib.import_module("simple-hrnet_amd.native")
-        lanes_eng = native.MultiDeviceHRNet([local] * a.lanes, a.c, 17, (a.height, a.width), a.dtype,
-                                            max_batch=min(a.max_batch, -(-a.batch // a.lanes)), model_name=a.model_name).adopt_from(net)
-
+    # the timed path: ONE engine per GPU, ONE stream.  (Two engines sharing the GPU with half of the batch each measure +2.3 ... +3.3 %
+    # in same-box pairs -- the `two_lanes` side measurement below -- and are NOT the headline: launches that overlap on the GPU cannot be
+    # timed one by one, so `roofline` and the rocprofv3 kernel statistics would no longer describe the timed path.  VERDICT r4 item 5.)
     def step():
-        if lanes_eng is None:
-            return eng.predict_crops_local_then_gather(images, boxes)
-        pts = lanes_eng.predict_crops(images, boxes)
-        if world == 1:
-            return pts
-        out = torch.empty((world * pts.shape[0],) + tuple(pts.shape[1:]), dtype=pts.dtype, device=pts.device)
-        eng._all_gather(out, pts)
-        return out
+        return eng.predict_crops_local_then_gather(images, boxes)
 
     for _ in range(a.warmup):
         step()
@@ -766,10 +761,6 @@ def main():
             ref.append(net.predict_crops(im, torch.from_numpy(pkg.synth_boxes(a.batch, seed=100 + r)).to(dev)))
         gather_ok = bool(torch.equal(torch.cat(ref, 0), pts))
         gather_ok = reduce_max(0.0 if gather_ok else 1.0) == 0.0
-    lanes_same = None
-    if lanes_eng is not None:   # the lanes only reschedule: same joints as ONE engine on the same crops
-        lanes_same = bool(torch.equal(pts[rank * a.batch:(rank + 1) * a.batch], net.predict_crops(images, boxes)))
-        assert lanes_same, "lanes changed the joints"
 
     out = None
     if rank == 0:
@@ -788,8 +779,8 @@ def main():
                                       " MFMA (BASELINE configs[2])" if (a.model_name, a.c, a.dtype, world) == ("HRNet", 48, "bf16", 1)
                                       else " MFMA, sharded over %d GPUs (BASELINE configs[3] shape: %d crops per step)" % (world, a.batch * world)
                                       if (a.model_name, a.c, a.dtype) == ("HRNet", 48, "bf16") else ""),
-                       "global_batch": a.batch * world, "micro_batch": a.max_batch if lanes_eng is None else lanes_eng.max_batch,
-                       "lanes_per_gpu": 1 if lanes_eng is None else a.lanes, "lanes_same_joints_as_one_engine": lanes_same,
+                       "global_batch": a.batch * world, "micro_batch": a.max_batch,
+                       "lanes_per_gpu": 1,
                        "parallelism": "dp%d (crop sharding, RCCL all-gather of keypoints)" % world,
                        "weights": "random-init seeded (synth_state_dict seed 0), BN stats randomised",
                        "engine_switches": net.switches()},
@@ -839,9 +830,9 @@ def main():
                 "source_hash": source_hash(),
             }
         # Side measurement, never `value`: the same step with TWO engines on this GPU, each on its own stream with half of the
-        # batch (native.MultiDeviceHRNet; what --lanes 2 times as the main path).  The launches of one engine fill the tails and
+        # batch (native.MultiDeviceHRNet).  The launches of one engine fill the tails and
         # drains of the other's: same kernels, same joints, twice the activation workspace.
-        if world == 1 and lanes_eng is None and not a.no_two_lanes and a.model_name == "HRNet" and a.batch >= 4:
+        if world == 1 and not a.no_two_lanes and a.model_name == "HRNet" and a.batch >= 4:
             try:
                 native = importlib.import_module("simple-hrnet_amd.native")
                 two = native.MultiDeviceHRNet([local, local], a.c, 17, (a.height, a.width), a.dtype,

@@ -20,11 +20,11 @@ ARGS = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "24", "--max-
         "--no-config1", "--no-fp32-w48", "--no-prepath", "--check-gather"]
 
 
-def _run(extra_env):
+def _run(extra_env, args=None):
     env = {k: v for k, v in os.environ.items() if not k.startswith("HRN_BENCH_")}
     env.update(extra_env)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + (args or ARGS), env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-2000:])
     return json.loads(lines[-1])
@@ -47,3 +47,23 @@ def test_bench_two_ranks_over_rccl():
     j = _run({})
     assert j["n_gpus"] == 2 and j["collective_backend"] == "nccl" and j["rccl_ranks"] == 2
     assert j["gathered_joints_equal_single_engine"] is True
+
+
+CLIP_ARGS = ["--gpus", "2", "--clip", "--max-batch", "8", "--check-gather"]
+
+
+def test_clip_two_ranks_sharing_gpu0_over_gloo():
+    """BASELINE configs[4] through the launcher -- the 30 frames dealt round-robin to two ranks, every rank's
+    joints summed over the ranks == the joints of ONE engine that is dealt every frame."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU: the HIP path has no CPU fallback"
+    j = _run({"HRN_BENCH_DEVICES": "0,0", "HRN_BENCH_BACKEND": "gloo"}, CLIP_ARGS)["clip"]
+    assert j["n_gpus"] == 2 and j["frames"] == 30 and j["persons"] == 240
+    assert j["gathered_joints_equal_single_engine"] is True and j["collective_backend"] == "gloo"
+    assert j["per_frame"]["fps"] > 0 and j["per_frame_sync"]["same_joints_as_per_frame"] is True
+
+
+def test_clip_two_ranks_over_rccl():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("ONE GPU on this box: the 2-rank RCCL run of the configs[4] clip was NOT exercised here")
+    j = _run({}, CLIP_ARGS)["clip"]
+    assert j["gathered_joints_equal_single_engine"] is True and j["collective_backend"] == "nccl"

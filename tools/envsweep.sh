@@ -7,6 +7,6 @@ mkdir -p "$out"
 i=0
 for setting in "$@"; do
   i=$((i+1))
-  env $setting timeout 120 python bench.py --steps 8 --warmup 2 --lanes 1 --no-clip --no-config1 --no-fp32-w48 --no-two-lanes --no-prepath --no-cpu-baseline > "$out/$i.json" 2> "$out/$i.err" < /dev/null
+  env $setting timeout 120 python bench.py --steps 8 --warmup 2 --no-clip --no-config1 --no-fp32-w48 --no-two-lanes --no-prepath --no-cpu-baseline > "$out/$i.json" 2> "$out/$i.err" < /dev/null
   python tools/abline.py "[$setting]" "$out/$i.json" < /dev/null
 done

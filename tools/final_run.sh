@@ -27,6 +27,13 @@ python tools/pmc_mean.py "$CSV" "conv_direct" > "$out/round${round}_pmc_direct.t
 python tools/pmc_mean.py "$CSV" "stem_fused_kernel" > "$out/round${round}_pmc_stem.txt" < /dev/null
 cat "$out/round${round}_pmc_wave.txt" "$out/round${round}_pmc_s2.txt"
 rm -rf "$out/stats" "$out/pmc_wave"
+# the first multi-GPU lease exercises RCCL without a code change: on a box with >= 2 GPUs the two nccl tests of
+# tests/test_multi_gpu.py ran above as part of the suite; say here which it was
+python - <<'PY' | tee "$out/round${round}_multi_gpu.txt"
+import torch
+n = torch.cuda.device_count()
+print("GPUs on this box: %d -> the 2-rank RCCL tests (bench.py --gpus 2, --clip) %s" % (n, "RAN in the suite above" if n >= 2 else "were SKIPPED (gloo variants ran)"))
+PY
 # LAST: the driver's smoke() on exactly this tree (it was red because nothing re-ran it after the last change)
 (timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; echo "smoke rc=$?" >> "$out/smoke.log") < /dev/null
 tail -n 6 "$out/smoke.log" | cut -c1-300

@@ -10,7 +10,7 @@ R=$PWD
 export TMPDIR=/tmp
 out=gpurun_out/pmc_traffic_r$round
 rm -rf "$out"; mkdir -p "$out"
-B="python bench.py --steps 1 --warmup 1 --lanes 1 --no-cpu-baseline --no-roofline --no-prepath --no-clip --no-config1 --no-fp32-w48 --no-two-lanes"
+B="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-prepath --no-clip --no-config1 --no-fp32-w48 --no-two-lanes"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$R/$out/fetch" -o f --output-format csv -- bash -c "cd $R && $B" > /dev/null 2>&1 < /dev/null)
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$R/$out/write" -o w --output-format csv -- bash -c "cd $R && $B" > /dev/null 2>&1 < /dev/null)
 # (written under gpurun_out/: that is what comes back from the GPU box; copy the three files into profiles/ afterwards)
