@@ -16,6 +16,15 @@
 //     it, and adds it -- the 0.9 GB tensor is neither written nor read.
 //   * No barrier after the weights are staged: each wave walks its own 16-pixel fragments (2 blocks = 8 waves per
 //     CU keep ~80 KiB of loads in flight, which is what the HBM pipe needs).
+//   * Round 5 (C3): the Bottleneck's 3x3 convolution (conv2 + bn2 + ReLU, 64 -> 64) in FRONT of conv3, for the blocks without a
+//     projection shortcut:  t2 = relu( W2 (*) t1 + b2 )  is computed per 16-pixel fragment from conv1's output t1 -- the nine taps
+//     are nine constant row shifts of the flat padded layout, 18 fragment loads of 16 B per lane that L1 / L2 serve (a pixel's
+//     128-byte row is one cache line, neighbouring taps share 15 of their 16 lines) -- in the GENERIC kernel's arithmetic
+//     (k = tap * 64 + ci in 32-wide chunks, accumulators from zero, bias added last; W2 in the generic image with NR = 2), so
+//     its D fragments, rounded to bf16 exactly where conv_direct_kernel would store them, ARE conv3's B operand: t2 (0.23 GB
+//     per 256 crops) is neither written nor read, and the launch of the 3x3 kernel (0.15 ms) is gone.  HBM traffic of the
+//     launch is unchanged (t1 is read instead of t2); W2 (72 KiB) joins W3 / W1' in LDS: one 8-wave block per CU.
+//     C3 = 2: the last Bottleneck of the layer -- no conv1 of a next block behind it.
 #include <stdlib.h>
 
 #include "kernels.h"
@@ -30,10 +39,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
+// C3 variants: 8 waves per block (12 -- the registers would allow three per SIMD -- measured 6 % slower, and so did requesting the
+// shortcut before the 3x3 instead of behind it: profiles/EXPERIMENTS.md, round 5)
+constexpr int C3_WAVES = 8;
 constexpr int CIN = 64, CMID = 256, COUT = 64;
 constexpr int W3_BYTES = CMID * CIN * 2, W1_BYTES = COUT * CMID * 2;
 constexpr int WDS_BYTES = CMID * CIN * 2;
-constexpr int lds_bytes(bool ds) { return W3_BYTES + W1_BYTES + CMID * 4 + COUT * 4 + (ds ? WDS_BYTES + CMID * 4 : 0); }
+constexpr int W2_CHUNKS = 18, W2_BYTES = 4 * W2_CHUNKS * 1024;   // conv2: 64 couts = 4 fragments, K = 9 taps x 64 = 18 chunks
+constexpr int lds_bytes(bool ds, int c3 = 0) {
+    return W3_BYTES + W1_BYTES + CMID * 4 + COUT * 4 + (ds ? WDS_BYTES + CMID * 4 : 0) + (c3 ? W2_BYTES + CIN * 4 : 0);
+}
 
 __device__ __forceinline__ float bf16_f32(short h) { return __uint_as_float(((unsigned)(unsigned short)h) << 16); }
 __device__ __forceinline__ short f32_bf16(float f) {  // round to nearest even, as every other store of the engine
@@ -45,25 +60,36 @@ __device__ __forceinline__ short f32_bf16(float f) {  // round to nearest even, 
 }  // namespace
 
 // DS = false: 4 waves, 66 KiB of LDS, two blocks per CU.  DS = true: 8 waves share 99 KiB, one block per CU.
-template <bool DS>
-__global__ __launch_bounds__(DS ? 512 : 256, DS ? 1 : 2) void bottleneck_chain_kernel(const ChainArgs p) {
+// C3 = 1 / 2 (DS = false): 8 waves share 138 KiB, one block per CU.
+template <bool DS, int C3 = 0>
+__global__ __launch_bounds__(C3 ? 64 * C3_WAVES : DS ? 512 : 256, C3 ? C3_WAVES / 4 : DS ? 1 : 2) void bottleneck_chain_kernel(const ChainArgs p) {
+    static_assert(!(DS && C3), "the 3x3 front exists for the blocks without a projection shortcut");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = DS ? 512 : 256, WAVES = NT / 64;
-    constexpr int DS_OFF = W3_BYTES + W1_BYTES + CMID * 4 + COUT * 4;  // [wds image][bds]
+    constexpr int NT = C3 ? 64 * C3_WAVES : DS ? 512 : 256, WAVES = NT / 64;
+    constexpr int DS_OFF = W3_BYTES + W1_BYTES + CMID * 4 + COUT * 4;  // [wds image][bds] / C3: [w2 image][b2]
     {
         const uint4 *w3 = (const uint4 *)p.w3, *w1 = (const uint4 *)p.w1;
         uint4 *d3 = (uint4 *)smem, *d1 = (uint4 *)(smem + W3_BYTES);
         for (int i = threadIdx.x; i < W3_BYTES / 16; i += NT) d3[i] = w3[i];
-        for (int i = threadIdx.x; i < W1_BYTES / 16; i += NT) d1[i] = w1[i];
+        if constexpr (C3 != 2)
+            for (int i = threadIdx.x; i < W1_BYTES / 16; i += NT) d1[i] = w1[i];
         float *b3 = (float *)(smem + W3_BYTES + W1_BYTES);
         for (int i = threadIdx.x; i < CMID; i += NT) b3[i] = p.b3[i];
-        if (threadIdx.x < COUT) b3[CMID + threadIdx.x] = p.b1[threadIdx.x];
+        if constexpr (C3 != 2)
+            if (threadIdx.x < COUT) b3[CMID + threadIdx.x] = p.b1[threadIdx.x];
         if constexpr (DS) {
             const uint4 *wd = (const uint4 *)p.wds;
             uint4 *dd = (uint4 *)(smem + DS_OFF);
             for (int i = threadIdx.x; i < WDS_BYTES / 16; i += NT) dd[i] = wd[i];
             float *bd = (float *)(smem + DS_OFF + WDS_BYTES);
             for (int i = threadIdx.x; i < CMID; i += NT) bd[i] = p.bds[i];
+        }
+        if constexpr (C3 != 0) {
+            const uint4 *w2 = (const uint4 *)p.w2;
+            uint4 *d2 = (uint4 *)(smem + DS_OFF);
+            for (int i = threadIdx.x; i < W2_BYTES / 16; i += NT) d2[i] = w2[i];
+            float *b2 = (float *)(smem + DS_OFF + W2_BYTES);
+            if (threadIdx.x < CIN) b2[threadIdx.x] = p.b2[threadIdx.x];
         }
     }
     __syncthreads();
@@ -93,9 +119,53 @@ __global__ __launch_bounds__(DS ? 512 : 256, DS ? 1 : 2) void bottleneck_chain_k
         const bool ok = live && ho < p.h && wo < p.w;
 
         s16x8 a[2], r[8];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) a[c] = *(const GLOBAL_AS s16x8 *)(in + (size_t)qc * CIN + c * 32 + g * 8);
         s16x8 wb[2][4];
+        if constexpr (C3 == 0) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) a[c] = *(const GLOBAL_AS s16x8 *)(in + (size_t)qc * CIN + c * 32 + g * 8);
+        } else {
+            // ---- t2 = relu(W2 (*) t1 + b2): 4 cout fragments x 18 K chunks (chunk kc = tap kc / 2, channels (kc & 1) * 32 + 8 g ..).
+            //      The tap fragments of one kernel row (6 chunks) are requested while the previous row's MFMAs run; the guard
+            //      rows of the buffer make every shifted row a valid address (pad positions hold zeros: the 3x3's zero padding).
+            const s16x8 *w2f = (const s16x8 *)(smem + DS_OFF) + lane;   // fragment (f, kc) at [(f * 18 + kc) * 64]
+            const float *b2s = (const float *)(smem + DS_OFF + W2_BYTES);
+            const GLOBAL_AS short *__restrict__ t1 = (const GLOBAL_AS short *)p.in3;
+            const GLOBAL_AS short *t1q = t1 + ((long)qc - p.wp - 1) * CIN + g * 8;   // tap (0, 0) of this lane's pixel
+            s16x8 xt[2][6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) xt[0][e] = *(const GLOBAL_AS s16x8 *)(t1q + (long)(e >> 1) * CIN + (e & 1) * 32);
+            f32x4 acc2[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc2[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) {
+                if (dh + 1 < 3) {
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+                        xt[(dh + 1) & 1][e] = *(const GLOBAL_AS s16x8 *)(t1q + ((long)(dh + 1) * p.wp + (e >> 1)) * CIN + (e & 1) * 32);
+                }
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const int kc = dh * 6 + e;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        acc2[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2f[(f * W2_CHUNKS + kc) * 64]),
+                                                                          __builtin_bit_cast(bf16x8, xt[dh & 1][e]), acc2[f], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // bias, ReLU, zero on pad pixels, round to bf16 -- conv_direct_kernel's epilogue, value for value; fragment f = 2 c + h
+            // row 4 g + r holds channel 32 c + 8 g + 4 h + r (generic image, NR = 2): the lane's eight values of K chunk c of conv3
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = acc2[2 * c + (e >> 2)][e & 3] + b2s[c * 32 + g * 8 + e];
+                    v = fmaxf(v, 0.f);
+                    if (!ok) v = 0.f;
+                    a[c][e] = f32_bf16(v);
+                }
+        }
         if constexpr (DS) {
             // shortcut = Wds * x + bds, rounded to bf16 (zero on pad pixels) like the tensor it replaces
             s16x8 xa[2];
@@ -172,6 +242,7 @@ __global__ __launch_bounds__(DS ? 512 : 256, DS ? 1 : 2) void bottleneck_chain_k
             }
             if (live) *(GLOBAL_AS s16x8 *)(out_y + (size_t)q * CMID + j * 32 + g * 8) = y[j];
         }
+        if constexpr (C3 == 2) continue;   // the layer's last Bottleneck: nothing behind conv3
         // ---- t' = W1' * y: 4 cout fragments x 8 K chunks, chunk kc's operand is y[kc]
         f32x4 acc2[4];
 #pragma unroll
@@ -205,26 +276,27 @@ __global__ __launch_bounds__(DS ? 512 : 256, DS ? 1 : 2) void bottleneck_chain_k
     }
 }
 
-template <bool DS>
+template <bool DS, int C3 = 0>
 static hipError_t launch_chain_t(const ChainArgs &a, hipStream_t s) {
     static std::atomic<unsigned long long> lds_set{0};   // per device: kernels.h set_dynamic_lds
     {
-        const hipError_t e = set_dynamic_lds((const void *)bottleneck_chain_kernel<DS>, lds_bytes(DS), lds_set);
+        const hipError_t e = set_dynamic_lds((const void *)bottleneck_chain_kernel<DS, C3>, lds_bytes(DS, C3), lds_set);
         if (e != hipSuccess) return e;
     }
     // persistent: 8 waves per CU re-use their staged weights over many 16-pixel fragments
     const int blocks_env = a.max_blocks > 0 ? a.max_blocks : 512;
-    constexpr int WAVES = DS ? 8 : 4;
+    constexpr int WAVES = C3 ? C3_WAVES : DS ? 8 : 4;
     const int mfrags = (a.m + 15) / 16;
     int blocks = (mfrags + WAVES - 1) / WAVES;
-    const int cap = DS ? blocks_env / 2 : blocks_env;
+    const int cap = (DS || C3) ? blocks_env / 2 : blocks_env;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(bottleneck_chain_kernel<DS>, dim3(blocks), dim3(64 * WAVES), lds_bytes(DS), s, a);
+    hipLaunchKernelGGL((bottleneck_chain_kernel<DS, C3>), dim3(blocks), dim3(64 * WAVES), lds_bytes(DS, C3), s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_bottleneck_chain(const ChainArgs &a, hipStream_t s) {
     if (a.m <= 0) return hipSuccess;
+    if (a.w2) return a.w1 ? launch_chain_t<false, 1>(a, s) : launch_chain_t<false, 2>(a, s);
     return a.wds ? launch_chain_t<true>(a, s) : launch_chain_t<false>(a, s);
 }
 

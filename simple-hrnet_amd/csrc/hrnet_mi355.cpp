@@ -54,7 +54,8 @@ struct hrn_ctx {
     std::vector<S2Group> s2groups;
     S2Problem *s2probs_dev = nullptr;   // (the problems of `s2groups`, then of `stemf`)
     struct Chain {
-        int conv3, conv1, ds;  // conv3 of Bottleneck b, conv1 of Bottleneck b+1, projection shortcut folded in (or -1)
+        int conv3, conv1, ds;  // conv3 of Bottleneck b, conv1 of Bottleneck b+1 (-1: none, the layer's last block), projection shortcut folded in (or -1)
+        int conv2 = -1;        // round 5: the 3x3 conv of Bottleneck b computed in front of conv3 (or -1: it has its own launch)
     };
     std::vector<Chain> chains;
     std::vector<TapPoint> taps;
@@ -79,6 +80,8 @@ struct hrn_ctx {
     // like every other switch -- not in a function-local static at the first launch)
     int pre_mode = env_sw("HRN_PRE_MODE") ? atoi(env_sw("HRN_PRE_MODE")) : 1;
     int chain_blocks = env_sw("HRN_CHAIN_BLOCKS") ? atoi(env_sw("HRN_CHAIN_BLOCKS")) : 512;
+    // round 5: the 3x3 conv of a Bottleneck without projection shortcut in front of its conv3 inside the chain kernel (off: its own launch)
+    bool disable_chain3 = env_sw("HRN_DISABLE_CHAIN3") != nullptr;
     bool direct_wlds = !(env_sw("HRN_DIRECT_WLDS") && atoi(env_sw("HRN_DIRECT_WLDS")) == 0);
     // fused BasicBlocks on the 48-channel branch (conv3x3_lds.hip: bbf_run): bit-identical, 2.5x less HBM traffic on that
     // branch, +2.6 % on the whole pass at 256 crops; HRN_BBF=0 goes back to two launches per block
@@ -730,12 +733,13 @@ int hrn_profile_pass(hrn_handle h, const void *images_dev, int n, float *conv_ms
                 for (int ci : g.conv_idx) tot += h->convs[ci].flops;
                 for (int ci : g.conv_idx)
                     if (conv_ms && ci < conv_ms_len) conv_ms[ci] = (float)(ms * h->convs[ci].flops / tot);
-            } else if (op.kind == OP_CHAIN) {  // two or three 1x1 convs of equal FLOPs
+            } else if (op.kind == OP_CHAIN) {  // 1x1 convs of equal FLOPs (+ the 3x3 in front of them): split by FLOPs
                 const hrn_ctx::Chain &ch = h->chains[op.idx];
-                const float share = ch.ds >= 0 ? ms / 3.f : ms * 0.5f;
-                if (conv_ms && ch.conv3 < conv_ms_len) conv_ms[ch.conv3] = share;
-                if (conv_ms && ch.conv1 < conv_ms_len) conv_ms[ch.conv1] = share;
-                if (conv_ms && ch.ds >= 0 && ch.ds < conv_ms_len) conv_ms[ch.ds] = share;
+                double tot = 0;
+                for (int ci : {ch.conv3, ch.conv1, ch.ds, ch.conv2})
+                    if (ci >= 0) tot += h->convs[ci].flops;
+                for (int ci : {ch.conv3, ch.conv1, ch.ds, ch.conv2})
+                    if (conv_ms && ci >= 0 && ci < conv_ms_len) conv_ms[ci] = (float)(ms * h->convs[ci].flops / tot);
             } else if (other_ms) {
                 const int slot = (op.kind == OP_STEM || op.kind == OP_STEM7 || op.kind == OP_MAXPOOL) ? 0 : op.kind == OP_FUSE ? 1 : op.kind == OP_HEAD ? 2 : 3;
                 other_ms[slot] += ms;

@@ -157,8 +157,11 @@ struct ChainArgs {
     void *out_t;           // conv1 output of block b+1: [rows][64]
     const void *w3;        // 256 x 64, generic fragment image with NR = 2
     const float *b3;
-    const void *w1;        // 64 x 256, generic fragment image with NR = 4
+    const void *w1;        // 64 x 256, generic fragment image with NR = 4 (nullptr with w2: the layer's last block, no next conv1)
     const float *b1;
+    const void *in3;       // round 5 (w2 != nullptr): conv1's output t1 [rows][64]; conv2 (3x3) is computed here, `in` is not read
+    const void *w2;        // 64 x 576, generic fragment image with NR = 2 (k = tap * 64 + ci), or nullptr
+    const float *b2;
     const void *x;         // block 0 only (wds != nullptr): the block input [rows][64]; the shortcut is Wds*x + bds
     const void *wds;       // 256 x 64, generic fragment image with NR = 2, or nullptr (shortcut read from `res`)
     const float *bds;

@@ -207,19 +207,21 @@ class NativeHRNet:
     def predict_stream(self, batches, return_heatmaps: bool = False):
         """Model call + decode for a sequence of HOST-resident batches with the uploads hidden behind the compute:
         batch k+1 crosses PCIe on a copy stream (two device staging buffers) while batch k runs on the current stream.
-        ``batches``: iterable of ``(images (n,3,H,W) float32 host tensor -- pinned memory for a truly asynchronous copy --,
-        boxes (n,4))`` with ``n <= max_batch``.  Yields, per batch, what ``predict_crops`` returns (results of batch k
+        ``batches``: iterable of ``(images, boxes (n,4))`` with ``n <= max_batch``; ``images`` is a HOST tensor (pinned memory for
+        a truly asynchronous copy), either ``(n,3,H,W) float32`` -- the normalised crops the reference builds on the CPU
+        (``SimpleHRNet.py:213-232``) -- or ``(n,H,W,3) uint8`` BGR crops already at the network's resolution (what ``cv2.resize``
+        leaves before ``cvtColor`` / ``ToTensor`` / ``Normalize``): a quarter of the bytes over PCIe (85 MB instead of 340 MB per
+        256 crops of 384x288), the colour flip and the normalisation then run on the GPU (``hrn_resize_frames`` at identity size:
+        the reference transform's float32 arithmetic).  Yields, per batch, what ``predict_crops`` returns (results of batch k
         are ready on the current stream; read them after a synchronize or through ``.cpu()``)."""
         dev = self.torch_device
         compute = torch.cuda.current_stream(dev)
         copy = torch.cuda.Stream(dev)
         h, w = self.resolution
-        stage = [torch.empty((self.max_batch, 3, h, w), dtype=torch.float32, device=dev) for _ in range(2)]
+        stage = [None, None]   # allocated for the first batch: fp32 NCHW or uint8 NHWC staging, by what the caller sends
         # the staging blocks come from the caching allocator on the COMPUTE stream and may be recycled memory that
         # kernels already queued there still read: the first upload must not overtake them
         copy.wait_stream(compute)
-        for t in stage:
-            t.record_stream(copy)
         landed = [torch.cuda.Event(), torch.cuda.Event()]
         consumed = [None, None]
 
@@ -230,12 +232,19 @@ class NativeHRNet:
             n = images.shape[0]
             if n > self.max_batch:
                 raise ValueError("a batch of %d crops exceeds max_batch=%d" % (n, self.max_batch))
+            u8 = images.dtype == torch.uint8
+            if u8 and tuple(images.shape[1:]) != (h, w, 3):
+                raise ValueError("uint8 crops must be (n, %d, %d, 3) BGR at the network's resolution" % (h, w))
+            want = (torch.uint8, (self.max_batch, h, w, 3)) if u8 else (torch.float32, (self.max_batch, 3, h, w))
+            if stage[slot] is None or stage[slot].dtype != want[0]:
+                stage[slot] = torch.empty(want[1], dtype=want[0], device=dev)
+                stage[slot].record_stream(copy)
             with torch.cuda.stream(copy):
                 if consumed[slot] is not None:
                     copy.wait_event(consumed[slot])              # the pass that read this buffer has finished
-                stage[slot][:n].copy_(images.to(torch.float32), non_blocking=True)
+                stage[slot][:n].copy_(images if u8 else images.to(torch.float32), non_blocking=True)
                 landed[slot].record(copy)
-            return n, boxes
+            return n, boxes, u8
 
         it = iter(batches)
         nxt = next(it, None)
@@ -243,11 +252,12 @@ class NativeHRNet:
         k = 0
         while pending is not None:
             slot = k & 1
-            n, boxes = pending
+            n, boxes, u8 = pending
             nxt = next(it, None)
             pending = upload(slot ^ 1, nxt) if nxt is not None else None   # goes out while this batch computes
             compute.wait_event(landed[slot])
-            out = self.predict_crops(stage[slot][:n], boxes, return_heatmaps=return_heatmaps)
+            x = self.resize_frames(stage[slot][:n], 0) if u8 else stage[slot][:n]   # (identity size: colour flip + ToTensor + Normalize)
+            out = self.predict_crops(x, boxes, return_heatmaps=return_heatmaps)
             consumed[slot] = torch.cuda.Event()
             consumed[slot].record(compute)
             yield out

@@ -251,7 +251,7 @@ def test_scheduling_variants_are_bit_identical(pkg, dtype, monkeypatch):
     boxes = pkg.synth_boxes(n, seed=22)
 
     def run(env):
-        for k in ("HRN_DISABLE_DGROUP", "HRN_DISABLE_CHAIN", "HRN_DISABLE_CHAIN_DS", "HRN_BBF", "HRN_BBF_MIN_TILES", "HRN_DIRECT_WLDS", "HRN_SMALL_TILES", "HRN_DGROUP_NR", "HRN_ALTERNATE", "HRN_DISABLE_GROUP", "HRN_DISABLE_FGROUP", "HRN_BLOCK_ORDER",
+        for k in ("HRN_DISABLE_DGROUP", "HRN_DISABLE_CHAIN", "HRN_DISABLE_CHAIN_DS", "HRN_DISABLE_CHAIN3", "HRN_BBF", "HRN_BBF_MIN_TILES", "HRN_DIRECT_WLDS", "HRN_SMALL_TILES", "HRN_DGROUP_NR", "HRN_ALTERNATE", "HRN_DISABLE_GROUP", "HRN_DISABLE_FGROUP", "HRN_BLOCK_ORDER",
                   "HRN_LONG_FACTOR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -263,7 +263,7 @@ def test_scheduling_variants_are_bit_identical(pkg, dtype, monkeypatch):
         return out
 
     base = run({})
-    for env in ({"HRN_DISABLE_DGROUP": "1"}, {"HRN_DISABLE_CHAIN": "1"}, {"HRN_DISABLE_CHAIN_DS": "1"}, {"HRN_BBF": "0"}, {"HRN_BBF_MIN_TILES": "1"}, {"HRN_DIRECT_WLDS": "0"}, {"HRN_SMALL_TILES": "0"}, {"HRN_DGROUP_NR": "0"}, {"HRN_ALTERNATE": "0"}, {"HRN_DISABLE_GROUP": "1"}, {"HRN_DISABLE_FGROUP": "1"},
+    for env in ({"HRN_DISABLE_DGROUP": "1"}, {"HRN_DISABLE_CHAIN": "1"}, {"HRN_DISABLE_CHAIN_DS": "1"}, {"HRN_DISABLE_CHAIN3": "1"}, {"HRN_BBF": "0"}, {"HRN_BBF_MIN_TILES": "1"}, {"HRN_DIRECT_WLDS": "0"}, {"HRN_SMALL_TILES": "0"}, {"HRN_DGROUP_NR": "0"}, {"HRN_ALTERNATE": "0"}, {"HRN_DISABLE_GROUP": "1"}, {"HRN_DISABLE_FGROUP": "1"},
                 {"HRN_BLOCK_ORDER": "0", "HRN_LONG_FACTOR": "1"}):
         hm, pts = run(env)
         np.testing.assert_array_equal(hm, base[0], err_msg=str(env))
@@ -289,6 +289,40 @@ def test_fused_basicblock_is_bit_identical(pkg, monkeypatch, h, w, n, mb):
         net.close()
     assert np.isfinite(outs[0][0]).all()
     assert outs[0][3] > 0 and outs[0][2] == outs[0][3] and outs[1][2] == 0   # all 32 BasicBlocks of the 48-channel branch went through the fused pass
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("model,c,h,w,n,mb", [("HRNet", 48, 384, 288, 5, 4), ("HRNet", 32, 256, 192, 33, 16), ("HRNet", 48, 64, 64, 9, 16),
+                                              ("HRNet", 48, 384, 288, 130, 130), ("PoseResNet", 50, 256, 192, 6, 4)])
+def test_bottleneck_3x3_inside_the_chain_kernel_is_bit_identical(pkg, monkeypatch, model, c, h, w, n, mb):
+    """Round 5 (bottleneck_chain.hip, C3): conv2 of the Bottlenecks without a projection shortcut computed in front of conv3 inside
+    the chain kernel -- against the same arithmetic as separate launches (HRN_DISABLE_CHAIN3=1: conv_direct_kernel + chain kernel):
+    the stored tensors behind it (conv3 of every block, conv1 of the next) and the heat-maps, bit for bit; ragged micro-batches;
+    the last block of the layer (no conv1 behind it); pad positions stay zero."""
+    crops = torch.from_numpy(pkg.synth_crops(n, h, w, seed=91)).cuda()
+    boxes = pkg.synth_boxes(n, seed=92)
+    outs = []
+    for on in (True, False):
+        monkeypatch.delenv("HRN_DISABLE_CHAIN3", raising=False)
+        if not on:
+            monkeypatch.setenv("HRN_DISABLE_CHAIN3", "1")
+        net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=mb, device=0, model_name=model).load_state_dict(
+            pkg.synth_state_dict(c, 17, 3, model=model))
+        tapped = {t.name.decode() for t in net.tap_infos()}
+        l1 = sorted(t for t in tapped if t.startswith("layer1."))
+        nb = 4 if model == "HRNet" else 3
+        assert (("layer1.1.conv2" in tapped), ("layer1.%d.conv2" % (nb - 1) in tapped), ("layer1.0.conv2" in tapped)) == ((not on), (not on), True)
+        hm, pts = net.predict_crops(crops, boxes, return_heatmaps=True)
+        x1 = crops[:min(n, mb)].contiguous()
+        taps = {t: net.forward_tap(x1, t).cpu().numpy() for t in l1 if t.endswith("conv3") or t.endswith("conv1")}
+        assert net.pad_violations() == 0
+        outs.append((hm.cpu().numpy(), pts.cpu().numpy(), taps))
+        net.close()
+    assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][0]).max() > 0
+    for t, v in outs[0][2].items():
+        np.testing.assert_array_equal(v, outs[1][2][t], err_msg=t)
+        assert np.abs(v).max() > 0, t
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
@@ -393,4 +427,22 @@ def test_predict_stream_hides_uploads_and_matches_predict_crops(pkg):
     assert list(net.predict_stream(iter([]))) == []
     with pytest.raises(ValueError):
         list(net.predict_stream([(torch.zeros((9, 3, h, w)), pkg.synth_boxes(9))]))
+    # round 5: uint8 BGR crops at the network's resolution (a quarter of the PCIe bytes; colour flip + ToTensor + Normalize on the GPU)
+    # -- mixed with fp32 batches in one stream, against the reference transform's float32 arithmetic done on the host
+    rng = np.random.default_rng(11)
+    items8, refs = [], []
+    for k, n in enumerate([8, 2, 5]):
+        u8 = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)                       # BGR, HWC (what cv2.resize leaves)
+        rgb = u8[..., ::-1].astype(np.float32) / np.float32(255.0)                       # cvtColor + ToTensor (SimpleHRNet.py:218-221, 167-172)
+        x = ((rgb - np.array([0.485, 0.456, 0.406], np.float32)) / np.array([0.229, 0.224, 0.225], np.float32)).transpose(0, 3, 1, 2)
+        b = pkg.synth_boxes(n, seed=90 + k)
+        items8.append((torch.from_numpy(u8).pin_memory(), b))
+        refs.append(net.predict_crops(torch.from_numpy(np.ascontiguousarray(x)).cuda(), b).cpu().numpy())
+        if k == 1:   # an fp32 batch in between: the staging buffers follow the dtype of what arrives
+            items8.append(items[0]), refs.append(outs[0][1])
+    got = [pts.cpu().numpy() for pts in net.predict_stream(iter(items8))]
+    for g, r in zip(got, refs):
+        np.testing.assert_array_equal(g, r)
+    with pytest.raises(ValueError):
+        list(net.predict_stream([(torch.zeros((2, h, w + 1, 3), dtype=torch.uint8), pkg.synth_boxes(2))]))
     net.close()

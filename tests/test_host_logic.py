@@ -185,7 +185,7 @@ def test_block_maps_cover_every_tile_at_other_resolutions(res, n, monkeypatch):
             fused_blocks += int(flags & 1)
         assert all((cov == 1).all() for cov in covered.values())
         group += 1
-    assert group == 69 and fused_blocks > 0
+    assert group == 66 and fused_blocks > 0
     net.close()
 
 
@@ -224,7 +224,7 @@ def test_block_maps_cover_every_tile_exactly_once(n, reverse):
             if fused:
                 fused_conv1.add(names[conv])
         group += 1
-    assert group == 69                                            # 64 BasicBlock launches + layer1's 4 + transition1
+    assert group == 66                                            # 64 BasicBlock launches + layer1.0's 3x3 + transition1 (round 5: the other 3x3s of layer1 run inside the chain kernel)
     hot = [k for k, nm in enumerate(names) if ".branches." in nm]
     big = -(-n * 97 * 73 // 512) >= 1100                          # hrn_ctx::bbf_min_tiles
     for k in hot:

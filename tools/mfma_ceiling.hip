@@ -25,7 +25,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int WST = 3 * 6 * 1024, SLAB = 44800, SB = 4 * WST, LDSB = SB + 2 * SLAB;
 constexpr int WP = 37;   // the 48x36 grid
 
-template <int V>
+// Stream T only.  ABL (timing-only ablations): 1 = no residual loads, 2 = no parked stores, 4 = no epilogue arithmetic.
+// LDM = where the 12 residual loads of a wave go: 0 one per slot over stages 6 and 7 (shipped), 1 one burst at the top of the last
+//       stage, 2 one burst at the top of stage 6, 3 three per stage over stages 4..7, 4 two per stage over stages 2..7
+// STM = where the 12 stores go: 0 one per slot under the next tile's first stage (shipped), 1 one burst at the tile end,
+//       2 six per stage over the next tile's stages 0 and 1, 3 three per stage over its stages 0..3
+template <int V, int ABL = 0, int LDM = 0, int STM = 0>
 __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *stamps, int stages, const unsigned *init, const char *src, char *big) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,14 +87,45 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
                         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[j]), "v"(xf[cc & 1][i]));
         } else {
             // (the kernel's counted wait: what this wave issued during the stage just finished may stay in flight, everything older has landed)
-            if constexpr (V >= 3) {
-                // (T: the residual loads / parked stores of the stage just finished may stay in flight too)
-                // (entering stage 7 / 8: the 6 residual loads of the stage before; entering stage 1: the 12 parked stores of stage 0)
-                if (V == 5 && (stage_in_tile == 7 || stage_in_tile == 8)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else if (V == 5 && stage_in_tile == 1 && s > 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            const bool tile2 = s * 3 + P >= 9;   // from the second tile on there are results to store
+            if constexpr (V == 3 || V == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if constexpr (V == 5) {
+                // extra vector-memory operations this wave issued during the stage just finished (besides its six pieces)
+                const int ps = stage_in_tile == 0 ? 8 : stage_in_tile - 1;
+                int ex = 0;
+                if (!(ABL & 1)) {
+                    if (LDM == 0) ex += (ps == 6 || ps == 7) ? 6 : 0;
+                    if (LDM == 1) ex += ps == 8 ? 12 : 0;
+                    if (LDM == 2) ex += ps == 6 ? 12 : 0;
+                    if (LDM == 3) ex += (ps >= 4 && ps <= 7) ? 3 : 0;
+                    if (LDM == 4) ex += (ps >= 2 && ps <= 7) ? 2 : 0;
+                }
+                if (!(ABL & 2) && tile2) {
+                    if (STM == 0) ex += ps == 0 ? 12 : 0;
+                    if (STM == 1) ex += ps == 8 ? 12 : 0;
+                    if (STM == 2) ex += ps <= 1 ? 6 : 0;
+                    if (STM == 3) ex += ps <= 3 ? 3 : 0;
+                }
+                switch (ex) {
+                    case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+                    case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                    case 8: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+                    case 12: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+                    case 24: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;   // (0, or stricter than needed)
+                }
             }
+#define T_LOAD(K) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rpre[(K) / 3][(K) % 3]) : "v"(lane16 + (unsigned)(K) * 1024u), "s"(bigb + bpos + 32768) : "memory")
+#define T_STORE(K) *(GLOBAL_AS u32x4 *)(bigb + bpos + 49152 + (K) * 1024 + lane16) = rpre[(K) / 3][(K) % 3]
             if constexpr (V >= 2) __builtin_amdgcn_s_barrier();
+            if constexpr (V == 5 && !(ABL & 1) && (LDM == 1 || LDM == 2)) {
+                if (stage_in_tile == (LDM == 1 ? 8 : 6)) {
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) T_LOAD(k);
+                }
+            }
             const unsigned sl_a = xrow0 + slab_par * SLAB;
             if (P == 0) {
 #pragma unroll
@@ -130,13 +166,37 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
                                 if (V >= 4 && sl >= 3) sp = bigb + bpos + (sl - 3) * 8192;
                                 asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane16), "s"(dst), "s"(sp) : "memory", "m0");
                             } else if (V == 5) {
-                                const int idx = (gi % 3 == 2 ? 6 : 0) + sl;   // 12 slots per stage besides the DMA ones
-                                if (stage_in_tile == 6 && gi % 3 == 2) {   // residual loads: 6 per stage over the two stages before the last
-                                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rpre[sl / 3][sl % 3]) : "v"(lane16 + (unsigned)sl * 1024u), "s"(bigb + bpos + 32768) : "memory");
-                                } else if (stage_in_tile == 7 && gi % 3 == 2) {
-                                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rpre[(6 + sl) / 3][(6 + sl) % 3]) : "v"(lane16 + (unsigned)(6 + sl) * 1024u), "s"(bigb + bpos + 32768) : "memory");
-                                } else if (stage_in_tile == 0 && s > 0) {                           // the previous tile's parked stores, one per slot
-                                    *(GLOBAL_AS u32x4 *)(bigb + bpos + 49152 + idx * 1024 + lane16) = rpre[idx / 3][idx % 3];
+                                const int st = stage_in_tile;
+                                if (gi % 3 == 2 && !(ABL & 1)) {   // residual loads (sl = 0..5 is the slot's number within the stage)
+                                    if (LDM == 0) {
+                                        if (st == 6) T_LOAD(sl);
+                                        else if (st == 7) T_LOAD(6 + sl);
+                                    } else if (LDM == 3 && sl % 2 == 0) {
+                                        if (st == 4) T_LOAD(sl / 2);
+                                        else if (st == 5) T_LOAD(3 + sl / 2);
+                                        else if (st == 6) T_LOAD(6 + sl / 2);
+                                        else if (st == 7) T_LOAD(9 + sl / 2);
+                                    } else if (LDM == 4 && sl % 3 == 0) {
+                                        if (st == 2) T_LOAD(sl / 3);
+                                        else if (st == 3) T_LOAD(2 + sl / 3);
+                                        else if (st == 4) T_LOAD(4 + sl / 3);
+                                        else if (st == 5) T_LOAD(6 + sl / 3);
+                                        else if (st == 6) T_LOAD(8 + sl / 3);
+                                        else if (st == 7) T_LOAD(10 + sl / 3);
+                                    }
+                                }
+                                if (!(ABL & 2) && tile2) {         // the previous tile's parked stores
+                                    if (STM == 0) {
+                                        if (st == 0) T_STORE((gi % 3 == 2 ? 6 : 0) + sl);
+                                    } else if (STM == 2 && gi % 3 == 2) {
+                                        if (st == 0) T_STORE(sl);
+                                        else if (st == 1) T_STORE(6 + sl);
+                                    } else if (STM == 3 && gi % 3 == 2 && sl % 2 == 0) {
+                                        if (st == 0) T_STORE(sl / 2);
+                                        else if (st == 1) T_STORE(3 + sl / 2);
+                                        else if (st == 2) T_STORE(6 + sl / 2);
+                                        else if (st == 3) T_STORE(9 + sl / 2);
+                                    }
                                 }
                             }
                         }
@@ -156,6 +216,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
                     asm volatile("s_nop 7\n\ts_nop 7\n\ts_waitcnt vmcnt(6)" ::: "memory");   // (the residual tile has landed; this stage's six pieces may stay in flight)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+                        if (ABL & 4) break;
                         unsigned pk[12];
 #pragma unroll
                         for (int j = 0; j < 6; ++j) {
@@ -176,6 +237,10 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
                         for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (STM == 1 && !(ABL & 2)) {
+#pragma unroll
+                        for (int idx = 0; idx < 12; ++idx) T_STORE(idx);
+                    }
                 }
             }
         }
@@ -194,20 +259,20 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
 static unsigned *g_init[2];
 static char *g_src[2];
 static char *g_big;
-template <int V>
+template <int V, int ABL = 0, int LDM = 0, int STM = 0>
 static void run(const char *name, int fill) {
     float *d; hipMalloc(&d, 256 * 512 * 4);
     long long *st; hipMalloc(&st, 256 * 16);
-    hipFuncSetAttribute((const void *)stream_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    hipFuncSetAttribute((const void *)stream_kernel<V, ABL, LDM, STM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     const int stages = 9000, blocks = 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    stream_kernel<V><<<blocks, 512, LDSB>>>(d, st, 60, g_init[fill], g_src[fill], g_big);
+    stream_kernel<V, ABL, LDM, STM><<<blocks, 512, LDSB>>>(d, st, 60, g_init[fill], g_src[fill], g_big);
     hipDeviceSynchronize();
     float best = 1e30f;
     double ticks = 0, mhz = 0;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        stream_kernel<V><<<blocks, 512, LDSB>>>(d, st, stages, g_init[fill], g_src[fill], g_big);
+        stream_kernel<V, ABL, LDM, STM><<<blocks, 512, LDSB>>>(d, st, stages, g_init[fill], g_src[fill], g_big);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) {
@@ -252,6 +317,23 @@ int main() {
             run<3>("D  B + 6 LDS-DMA pieces per wave and stage", fill);
             run<4>("H  D, slab pieces streamed from HBM", fill);
             run<5>("T  H + residual loads, epilogue, parked stores every 9 stages", fill);
+            if (fill == 0) {
+                run<5, 1>("T - residual loads", fill);
+                run<5, 2>("T - parked stores", fill);
+                run<5, 4>("T - epilogue arithmetic", fill);
+                run<5, 7>("T - all three (the per-tile control flow alone)", fill);
+                run<5, 0, 0, 1>("T: stores in one burst at the tile end", fill);
+                run<5, 0, 0, 2>("T: stores 6 + 6 over the next tile's stages 0-1", fill);
+                run<5, 0, 0, 3>("T: stores 3 per stage over the next tile's stages 0-3", fill);
+                run<5, 0, 1, 0>("T: residual loads in one burst at the top of the last stage", fill);
+                run<5, 0, 2, 0>("T: residual loads in one burst at the top of stage 6", fill);
+                run<5, 0, 3, 0>("T: residual loads 3 per stage over stages 4-7", fill);
+                run<5, 0, 4, 0>("T: residual loads 2 per stage over stages 2-7", fill);
+                run<5, 0, 1, 1>("T: loads burst (last stage) + stores burst", fill);
+                run<5, 0, 2, 1>("T: loads burst (stage 6) + stores burst", fill);
+                run<5, 0, 3, 3>("T: loads 3 per stage (4-7) + stores 3 per stage (0-3)", fill);
+                run<5, 0, 4, 1>("T: loads 2 per stage (2-7) + stores burst", fill);
+            }
         }
     return 0;
 }
