@@ -25,6 +25,7 @@ python tools/pmc_mean.py "$CSV" "conv3x3_lds_kernel<48" > "$out/round${round}_pm
 python tools/pmc_mean.py "$CSV" "conv_s2_slab_kernel" > "$out/round${round}_pmc_s2.txt" < /dev/null
 python tools/pmc_mean.py "$CSV" "conv_direct" > "$out/round${round}_pmc_direct.txt" < /dev/null
 python tools/pmc_mean.py "$CSV" "stem_fused_kernel" > "$out/round${round}_pmc_stem.txt" < /dev/null
+python tools/pmc_mean.py "$CSV" "bottleneck_chain_kernel" > "$out/round${round}_pmc_chain.txt" < /dev/null
 cat "$out/round${round}_pmc_wave.txt" "$out/round${round}_pmc_s2.txt"
 rm -rf "$out/stats" "$out/pmc_wave"
 # the first multi-GPU lease exercises RCCL without a code change: on a box with >= 2 GPUs the two nccl tests of
