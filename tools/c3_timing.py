@@ -36,9 +36,11 @@ if len(n96):
         pro, pro_issue = (sel[:, :, 1] >> 32).astype(float), (sel[:, :, 3] >> 32).astype(float)
         ewait = (sel[:, :, 3] & 0xffffffff).astype(float)
         print("    block prologue (entry -> first stage): %.0f ticks, of which setup + LDS-DMA issue %.0f" % (pro[:, 0].mean(), pro_issue[:, 0].mean()))
+        rt = (sel[:, 0, 0] >> 32).astype(float)   # the block's life in 100-MHz ticks (s_memrealtime)
+        print("    shader clock while these blocks ran: %.0f MHz (s_memtime / s_memrealtime)" % (100.0 * sel[:, 0, 4].sum() / max(1.0, rt.sum())))
         for w in range(8):
             print("    wave %d: per stage: entry wait %.0f  plan/residual issue %.0f  chunks %.0f | per tile: residual wait %.0f  epilogue rest %.0f | prologue %.0f (issue %.0f)" % (
-                w, (sel[:, w, 0] / st[:, w]).mean(), (plan[:, w] / st[:, w]).mean(), (sel[:, w, 2] / st[:, w]).mean(),
+                w, ((sel[:, w, 0] & 0xffffffff) / st[:, w]).mean(), (plan[:, w] / st[:, w]).mean(), (sel[:, w, 2] / st[:, w]).mean(),
                 (ewait[:, w] / nt[:, w]).mean(), (erest[:, w] / nt[:, w]).mean(), pro[:, w].mean(), pro_issue[:, w].mean()))
     buf[(buf[:, 0, 6] >= 90) & (buf[:, 0, 6] < 100)] = 0
 fz = buf[buf[:, 0, 6] >= 100]   # fused BasicBlock blocks (bbf_run) record their own phases
