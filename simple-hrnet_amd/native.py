@@ -237,8 +237,11 @@ class NativeHRNet:
                 raise ValueError("uint8 crops must be (n, %d, %d, 3) BGR at the network's resolution" % (h, w))
             want = (torch.uint8, (self.max_batch, h, w, 3)) if u8 else (torch.float32, (self.max_batch, 3, h, w))
             if stage[slot] is None or stage[slot].dtype != want[0]:
+                # a staging block comes from the caching allocator on the COMPUTE stream and may be recycled memory that kernels already
+                # queued there still read: the upload into it must not overtake them
                 stage[slot] = torch.empty(want[1], dtype=want[0], device=dev)
                 stage[slot].record_stream(copy)
+                copy.wait_stream(compute)
             with torch.cuda.stream(copy):
                 if consumed[slot] is not None:
                     copy.wait_event(consumed[slot])              # the pass that read this buffer has finished
