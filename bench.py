@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--no-fp32-w48", action="store_true", help="skip the fp32 line on the headline shape")
     ap.add_argument("--clip", action="store_true", help="ONLY the configs[4] clip measurement (its JSON line is the clip block)")
     ap.add_argument("--check-gather", action="store_true", help="N > 1: compare the all-gathered joints with one engine run over every rank's crops")
+    ap.add_argument("--zeros", action="store_true",
+                    help="DIAGNOSTIC (never the metric): all-zero weights, BN shifts and crops -- every MFMA operand is zero, so the part's "
+                         "power budget is out of the picture; against the random run on the same box it tells a power-bound kernel (>= 15 %% faster) "
+                         "from a stall-bound one (VERDICT r5 item 1a)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -740,7 +744,11 @@ def main():
 
     net = pkg.NativeHRNet(a.c, 17, (a.height, a.width), a.dtype, max_batch=a.max_batch, device=local, model_name=a.model_name)
     eng = shard.ShardedHRNet(net, dist)
-    eng.load_and_broadcast(pkg.synth_state_dict(a.c, 17, 0, model=a.model_name) if rank == 0 else None, src=0)
+    sd0 = pkg.synth_state_dict(a.c, 17, 0, model=a.model_name) if rank == 0 else None
+    if a.zeros and sd0 is not None:   # zero operands everywhere: weights, BN shift / mean (var 1 keeps the fold finite), biases
+        sd0 = type(sd0)((k, (np.ones_like(v) if k.endswith("running_var") else np.zeros_like(v))) for k, v in sd0.items())
+    eng.load_and_broadcast(sd0, src=0)
+    del sd0
 
     if a.clip:   # only the configs[4] measurement
         cpu = None
@@ -764,6 +772,8 @@ def main():
     # synthetic crops, device resident (post-normalisation domain ~N(0,1)), different per rank
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn((a.batch, 3, a.height, a.width), generator=g, device=dev, dtype=torch.float32)
+    if a.zeros:
+        images.zero_()
     boxes_np = pkg.synth_boxes(a.batch, seed=100 + rank)
     boxes = torch.from_numpy(boxes_np).to(dev)
 
@@ -814,7 +824,7 @@ def main():
             "metric": "person-crops/sec %s %dx%d (model forward + heat-map decode)" % (name, a.height, a.width),
             "value": round(value, 2), "unit": "crops/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic" if not a.zeros else "ZEROS (diagnostic run: not the metric)",
             "config": {"workload": "%s %dx%d, batch=%d random crops per GPU, %s%s"
                                    % (name, a.height, a.width, a.batch, a.dtype,
                                       " MFMA (BASELINE configs[2])" if (a.model_name, a.c, a.dtype, world) == ("HRNet", 48, "bf16", 1)

@@ -46,6 +46,15 @@ def _obj(src: str) -> str:
 
 
 def _stamp() -> str:
+    """cached per flag set: `hipcc --version` is a subprocess, and needs_build() / _stale() ask once per source"""
+    return _stamp_of(tuple(HIPCC_FLAGS))
+
+
+import functools  # noqa: E402
+
+
+@functools.lru_cache(maxsize=None)
+def _stamp_of(flags) -> str:
     """what the objects of this library were compiled WITH: the flags (a tagged variant adds -D flags) and the compiler's version
     (objects built under other flags must not be reused because their sources are older)"""
     import hashlib
@@ -53,7 +62,7 @@ def _stamp() -> str:
         ver = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
     except Exception:  # noqa: BLE001 -- no compiler: needs_build() decides whether that matters
         ver = "?"
-    return hashlib.sha256((" ".join(HIPCC_FLAGS) + "\n" + ver).encode()).hexdigest()
+    return hashlib.sha256((" ".join(flags) + "\n" + ver).encode()).hexdigest()
 
 
 def _stamp_ok() -> bool:
@@ -98,7 +107,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     import fcntl
     from concurrent.futures import ThreadPoolExecutor
 
-    with open(LIB_PATH + ".lock", "w") as lock:
+    # (the lock lives with the objects, not beside the library: nine stale `*.so.lock` files used to ship with every push)
+    os.makedirs(_obj_dir(), exist_ok=True)
+    with open(os.path.join(_obj_dir(), "build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if force or needs_build():

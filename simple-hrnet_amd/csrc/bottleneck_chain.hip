@@ -288,7 +288,7 @@ static hipError_t launch_chain_t(const ChainArgs &a, hipStream_t s) {
     constexpr int WAVES = C3 ? C3_WAVES : DS ? 8 : 4;
     const int mfrags = (a.m + 15) / 16;
     int blocks = (mfrags + WAVES - 1) / WAVES;
-    const int cap = (DS || C3) ? blocks_env / 2 : blocks_env;
+    const int cap = (DS || C3) ? (blocks_env / 2 > 1 ? blocks_env / 2 : 1) : blocks_env;   // (HRN_CHAIN_BLOCKS < 2 must not give a zero grid)
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((bottleneck_chain_kernel<DS, C3>), dim3(blocks), dim3(64 * WAVES), lds_bytes(DS, C3), s, a);
     return hipGetLastError();

@@ -50,12 +50,9 @@ def _launcher_local_rank() -> Optional[int]:
     SLURM_LOCALID runs 0..7."""
     ndev = max(1, torch.cuda.device_count())
     if "LOCAL_RANK" in os.environ:
-        lr = int(os.environ["LOCAL_RANK"])
-        # (ADVICE r4) torchrun does not restrict the visible devices: a local rank beyond them is a launch error, said here
-        # rather than as an invalid-device failure deep inside the engine
-        if lr < 0 or (torch.cuda.is_available() and lr >= ndev):
-            raise ValueError("LOCAL_RANK=%d but this process sees %d GPU(s): launch at most one rank per visible GPU" % (lr, ndev))
-        return lr
+        # (taken as it is: whether it names a visible device is checked where it is USED as the device index -- _check_local_rank;
+        # an explicit 'cuda:i[,j]' list maps it with a modulo instead, ADVICE r5)
+        return int(os.environ["LOCAL_RANK"])
     for key, sizes in _LAUNCHERS:
         if key in os.environ:
             counts = [int(os.environ[k]) for k in sizes if os.environ.get(k, "").isdigit()]
@@ -70,6 +67,16 @@ def _launcher_local_rank() -> Optional[int]:
     return None
 
 
+def _check_local_rank(lr: int) -> int:
+    """ torchrun does not restrict the visible devices: a local rank used DIRECTLY as the device index (device
+    None / 'cuda' / torch.device('cuda')) beyond them is a launch error, said here rather than as an invalid-device failure deep
+    inside the engine.  Explicit lists ('cuda:0', 'cuda:0,0', one visible GPU per rank) never come through here."""
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if lr < 0 or (ndev and lr >= ndev):
+        raise ValueError("LOCAL_RANK=%d but this process sees %d GPU(s): launch at most one rank per visible GPU" % (lr, ndev))
+    return lr
+
+
 def resolve_device(device, local_rank: Optional[int] = None) -> torch.device:
     """The reference's device argument (``SimpleHRNet.py:123-139``) mapped onto one-process-per-GPU: ``'cuda:3'`` is that
     GPU; ``'cuda'`` (all GPUs through DataParallel there) and ``'cuda:1,2'`` (the listed ones) name the set this job runs
@@ -78,14 +85,14 @@ def resolve_device(device, local_rank: Optional[int] = None) -> torch.device:
     if local_rank is None:
         local_rank = _launcher_local_rank() or 0
     if device is None:
-        return torch.device("cuda", local_rank)
+        return torch.device("cuda", _check_local_rank(local_rank))
     if isinstance(device, torch.device):
         if device.type != "cuda":
             raise ValueError("the MI355X engine has no CPU path (device=%s)" % device)
-        return torch.device("cuda", local_rank if device.index is None else device.index)
+        return torch.device("cuda", _check_local_rank(local_rank) if device.index is None else device.index)
     name = str(device)
     if name == "cuda":
-        return torch.device("cuda", local_rank)
+        return torch.device("cuda", _check_local_rank(local_rank))
     if name.startswith("cuda:"):
         try:
             ids = [int(x) for x in name[5:].split(",")]

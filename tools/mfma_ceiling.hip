@@ -30,7 +30,10 @@ constexpr int WP = 37;   // the 48x36 grid
 //       stage, 2 one burst at the top of stage 6, 3 three per stage over stages 4..7, 4 two per stage over stages 2..7
 // STM = where the 12 stores go: 0 one per slot under the next tile's first stage (shipped), 1 one burst at the tile end,
 //       2 six per stage over the next tile's stages 0 and 1, 3 three per stage over its stages 0..3
-template <int V, int ABL = 0, int LDM = 0, int STM = 0>
+// PITCH (round 6): 0 = every vector-memory instruction moves one contiguous KiB (round 5's streams); > 0 = the kernel's real access
+//       shape on an NHWC tensor whose pixel rows are PITCH bytes apart -- an LDS-DMA slab piece is 16 pixel rows x 64 bytes (one
+//       32-channel slice, slice after slice of the same rows), a residual load / store 16 pixel rows x 64 bytes
+template <int V, int ABL = 0, int LDM = 0, int STM = 0, int PITCH = 0>
 __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *stamps, int stages, const unsigned *init, const char *src, char *big) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,6 +70,10 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
     // H / T: this block's 8-MB window of the big region (slab pieces, residual tile, stores)
     GLOBAL_AS char *const bigb = (GLOBAL_AS char *)big + (size_t)blockIdx.x * (8u << 20);
     unsigned bpos = wave * 1024;   // running byte offset inside the window (wraps at 8 MB - 64 KB)
+    // PITCH > 0: lane offsets of a slab piece (16 rows x four 16-byte slots) and of a residual / store piece (pixel li, k-group g)
+    const unsigned voff_dma = PITCH ? (unsigned)((wave * 16 + (lane >> 2)) * PITCH + (lane & 3) * 16) : lane16;
+    const unsigned voff_px = PITCH ? (unsigned)((wave * 64 + li) * PITCH + g * 16) : lane16;
+    unsigned tile_row = 0, slice_col = 0;   // PITCH > 0: first pixel row of the tile in work, byte column of the slice in work
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     u32x4 rpre[4][3];
 #pragma unroll
@@ -117,8 +124,18 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
                     default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;   // (0, or stricter than needed)
                 }
             }
-#define T_LOAD(K) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rpre[(K) / 3][(K) % 3]) : "v"(lane16 + (unsigned)(K) * 1024u), "s"(bigb + bpos + 32768) : "memory")
-#define T_STORE(K) *(GLOBAL_AS u32x4 *)(bigb + bpos + 49152 + (K) * 1024 + lane16) = rpre[(K) / 3][(K) % 3]
+#define T_LOAD(K)                                                                                                                     \
+    do {                                                                                                                                 \
+        if constexpr (PITCH == 0)                                                                                                     \
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rpre[(K) / 3][(K) % 3]) : "v"(lane16 + (unsigned)(K) * 1024u), "s"(bigb + bpos + 32768) : "memory"); \
+        else                                                                                                                          \
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rpre[(K) / 3][(K) % 3]) : "v"(voff_px + (unsigned)(((K) / 3) * 16 * PITCH + ((K) % 3) * 64)), "s"(bigb + (5u << 19) + tile_row * PITCH) : "memory"); \
+    } while (0)
+#define T_STORE(K)                                                                                                                    \
+    do {                                                                                                                                 \
+        if constexpr (PITCH == 0) *(GLOBAL_AS u32x4 *)(bigb + bpos + 49152 + (K) * 1024 + lane16) = rpre[(K) / 3][(K) % 3];          \
+        else *(GLOBAL_AS u32x4 *)(bigb + (5u << 20) + tile_row * PITCH + voff_px + ((K) / 3) * 16 * PITCH + ((K) % 3) * 64) = rpre[(K) / 3][(K) % 3]; \
+    } while (0)
             if constexpr (V >= 2) __builtin_amdgcn_s_barrier();
             if constexpr (V == 5 && !(ABL & 1) && (LDM == 1 || LDM == 2)) {
                 if (stage_in_tile == (LDM == 1 ? 8 : 6)) {
@@ -164,7 +181,12 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
                                 const unsigned dst = sl < 3 ? wdst + sl * 8192 : sdst + (sl - 3) * 8192;
                                 const GLOBAL_AS char *sp = gsrc + sl * 8192;
                                 if (V >= 4 && sl >= 3) sp = bigb + bpos + (sl - 3) * 8192;
-                                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane16), "s"(dst), "s"(sp) : "memory", "m0");
+                                unsigned vo = lane16;
+                                if (PITCH && V >= 4 && sl >= 3) {   // piece (P, sl - 3) of this slice's slab: 128 rows further per piece
+                                    sp = bigb + (size_t)(tile_row + (P * 3 + sl - 3) * 128) * PITCH + slice_col;
+                                    vo = voff_dma;
+                                }
+                                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(vo), "s"(dst), "s"(sp) : "memory", "m0");
                             } else if (V == 5) {
                                 const int st = stage_in_tile;
                                 if (gi % 3 == 2 && !(ABL & 1)) {   // residual loads (sl = 0..5 is the slot's number within the stage)
@@ -209,6 +231,13 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
             if constexpr (V >= 4) {
                 bpos += 3 * 8192;
                 if (bpos > (8u << 20) - 131072u) bpos = wave * 1024;
+                if (PITCH && P == 2) {   // next slice of the same rows; after the last slice the next tile's rows
+                    slice_col += 64;
+                    if (slice_col >= (unsigned)PITCH) {
+                        slice_col = 0, tile_row += 1152;
+                        if ((tile_row + 2400) * PITCH > (2u << 20)) tile_row = 0;   // (slab pieces [0, 2 MB), residual tile [2.5, 4.5 MB), stores [5, 7 MB) of the 8-MB window)
+                    }
+                }
             }
             if constexpr (V == 5) {
                 if (++stage_in_tile == 9) {   // tile end: the epilogue (residual add, ReLU / pad mask, pack), results parked in rpre
@@ -259,20 +288,21 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
 static unsigned *g_init[2];
 static char *g_src[2];
 static char *g_big;
-template <int V, int ABL = 0, int LDM = 0, int STM = 0>
+static int g_blocks = 256;
+template <int V, int ABL = 0, int LDM = 0, int STM = 0, int PITCH = 0>
 static void run(const char *name, int fill) {
     float *d; hipMalloc(&d, 256 * 512 * 4);
     long long *st; hipMalloc(&st, 256 * 16);
-    hipFuncSetAttribute((const void *)stream_kernel<V, ABL, LDM, STM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-    const int stages = 9000, blocks = 256;
+    hipFuncSetAttribute((const void *)stream_kernel<V, ABL, LDM, STM, PITCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    const int stages = 9000, blocks = g_blocks;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    stream_kernel<V, ABL, LDM, STM><<<blocks, 512, LDSB>>>(d, st, 60, g_init[fill], g_src[fill], g_big);
+    stream_kernel<V, ABL, LDM, STM, PITCH><<<blocks, 512, LDSB>>>(d, st, 60, g_init[fill], g_src[fill], g_big);
     hipDeviceSynchronize();
     float best = 1e30f;
     double ticks = 0, mhz = 0;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        stream_kernel<V, ABL, LDM, STM><<<blocks, 512, LDSB>>>(d, st, stages, g_init[fill], g_src[fill], g_big);
+        stream_kernel<V, ABL, LDM, STM, PITCH><<<blocks, 512, LDSB>>>(d, st, stages, g_init[fill], g_src[fill], g_big);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) {
@@ -280,8 +310,8 @@ static void run(const char *name, int fill) {
             std::vector<long long> h(512);
             hipMemcpy(h.data(), st, 4096, hipMemcpyDeviceToHost);
             double a = 0, b = 0;
-            for (int i = 0; i < 256; ++i) a += h[2 * i], b += h[2 * i + 1];
-            ticks = a / 256 / stages, mhz = a / b * 100.0;
+            for (int i = 0; i < blocks; ++i) a += h[2 * i], b += h[2 * i + 1];
+            ticks = a / blocks / stages, mhz = a / b * 100.0;
         }
     }
     const double flop = (double)blocks * 8 * stages * 72.0 * 16384.0;
@@ -291,7 +321,12 @@ static void run(const char *name, int fill) {
     hipFree(d); hipFree(st);
 }
 
-int main() {
+int main(int argc, char **argv) {
+    // mfma_ceiling [blocks] [mode]: blocks = CUs in use (256; 64 = a quarter of the chip, which then clocks at ~2.3 GHz like the kernel in
+    // the net -- VERDICT r5 item 1b); mode 0 = round 5's full table, 1 = the short table P / D / H / T + the strided-access streams
+    if (argc > 1) g_blocks = atoi(argv[1]);
+    const int mode = argc > 2 ? atoi(argv[2]) : 0;
+    printf("blocks = %d (one 512-thread block per CU)\n", g_blocks);
     std::vector<unsigned> h(LDSB / 4), z(LDSB / 4, 0u);
     srand(1);
     for (auto &x : h) {   // two random bf16 in [-2, 2): sign, exponent 125..128, random mantissa
@@ -309,6 +344,20 @@ int main() {
     }
     hipMalloc(&g_big, (size_t)256 * (8u << 20));
     hipMemset(g_big, 0x3c, (size_t)256 * (8u << 20));
+    if (mode == 1) {
+        for (int rep = 0; rep < 2; ++rep)
+            for (int fill = 0; fill < 2; ++fill) {
+                run<0>("P  MFMAs only (the known-good stream)", fill);
+                run<3>("D  stage loop + barrier + 6 LDS-DMA pieces (L2 source)", fill);
+                run<4>("H  D, slab pieces streamed from HBM, contiguous KiB", fill);
+                run<4, 0, 0, 0, 192>("H192  slab pieces = 16 rows x 64 B at a 192-B pitch", fill);
+                run<4, 0, 0, 0, 768>("H768  slab pieces = 16 rows x 64 B at a 768-B pitch", fill);
+                run<5>("T  H + residual loads, epilogue, stores every 9 stages", fill);
+                run<5, 0, 0, 0, 192>("T192  T with every access 16 rows x 64 B, 192-B pitch", fill);
+                run<5, 7, 0, 0, 192>("T192 - all three (per-tile control flow alone)", fill);
+            }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep)
         for (int fill = 0; fill < 2; ++fill) {
             run<0>("P  MFMAs only (the known-good stream)", fill);
