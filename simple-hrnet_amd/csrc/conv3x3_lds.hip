@@ -81,6 +81,12 @@ struct C3Cfg {
     static_assert(LDS <= 160 * 1024 - 256, "LDS budget");
 };
 
+#ifdef HRN_Q_TIMING   // debug (tools/cu_timeline.py): per block -- which CU ran it, from when to when (s_memrealtime, 100 MHz), of the last four launches
+__device__ long long *g_q_timing = nullptr;
+__device__ int g_q_seq = 0;
+__global__ void q_seq_bump() { ++g_q_seq; }
+constexpr int kQSlots = 4, kQBlocks = 8192;
+#endif
 #ifdef HRN_C3_TIMING
 #define C3_T(x) const long long x = __builtin_amdgcn_s_memtime()
 __device__ long long *g_c3_timing = nullptr;
@@ -834,8 +840,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_lds_kernel(const Conv3Problem 
             if (g_q_timing && threadIdx.x == 0) {
                 unsigned hw, xcc;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-                g_q_timing[blockIdx.x * 4 + 0] = t0, g_q_timing[blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
-                g_q_timing[blockIdx.x * 4 + 3] = (long long)(((xcc & 15u) << 16) | (hw & 0xff00u));   // XCC, SE / SH / CU bits of HW_ID
+                const int seq = g_q_seq;
+                long long *o = g_q_timing + ((size_t)(seq & (kQSlots - 1)) * kQBlocks + (blockIdx.x < kQBlocks ? blockIdx.x : kQBlocks - 1)) * 4;
+                o[0] = t0, o[1] = (long long)gridDim.x | ((long long)seq << 32), o[2] = (long long)__builtin_amdgcn_s_memrealtime();
+                o[3] = (long long)(((xcc & 15u) << 16) | (hw & 0xff00u));   // XCC, SE / SH / CU bits of HW_ID
             }
         }
     } stamp_;
@@ -897,6 +905,23 @@ extern "C" int hrn_debug_c3_timing(long long *host_out, int max_blocks) {
 }
 #endif
 
+#ifdef HRN_Q_TIMING
+// first call: allocate + arm; later calls: copy out [slot][block][4] = {t0, grid | seq << 32, t1, CU id}
+extern "C" int hrn_debug_q_timing(long long *host_out) {
+    static long long *buf = nullptr;
+    const size_t bytes = (size_t)kQSlots * kQBlocks * 4 * sizeof(long long);
+    if (!buf) {
+        if (hipMalloc((void **)&buf, bytes) != hipSuccess) return -1;
+        (void)hipMemset(buf, 0, bytes);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_q_timing), &buf, sizeof(buf));
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host_out, buf, bytes, hipMemcpyDeviceToHost);
+    return 1;
+}
+#endif
+
 template <int KS, int NRB>
 static hipError_t launch_c3(const Conv3Problem *probs_dev, const int2 *blockmap_dev, int nblocks, int nb, hipStream_t s) {
     using CFG = C3Cfg<KS, NRB>;
@@ -908,6 +933,9 @@ static hipError_t launch_c3(const Conv3Problem *probs_dev, const int2 *blockmap_
         const hipError_t e = set_dynamic_lds((const void *)conv3x3_lds_kernel<KS, NRB>, LDS, lds_set);
         if (e != hipSuccess) return e;
     }
+#ifdef HRN_Q_TIMING
+    hipLaunchKernelGGL(q_seq_bump, dim3(1), dim3(1), 0, s);
+#endif
     hipLaunchKernelGGL((conv3x3_lds_kernel<KS, NRB>), dim3(nblocks), dim3(512), LDS, s, probs_dev, blockmap_dev, nb);
     return hipGetLastError();
 }

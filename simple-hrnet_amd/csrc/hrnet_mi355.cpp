@@ -83,6 +83,13 @@ struct hrn_ctx {
     // round 5: the 3x3 conv of a Bottleneck without projection shortcut in front of its conv3 inside the chain kernel (off: its own launch)
     bool disable_chain3 = env_sw("HRN_DISABLE_CHAIN3") != nullptr;
     bool direct_wlds = !(env_sw("HRN_DIRECT_WLDS") && atoi(env_sw("HRN_DIRECT_WLDS")) == 0);
+    // round 6: stride-2 3x3 convolutions with cin % 32 == 0 on the generic kernel request their pixel fragments two K chunks ahead by
+    // LDS-DMA into a per-wave LDS ring (kernels.hip: XL); same arithmetic in the same order: bit-identical to HRN_DIRECT_XLDS=0
+    bool direct_xlds = !(env_sw("HRN_DIRECT_XLDS") && atoi(env_sw("HRN_DIRECT_XLDS")) == 0);
+    bool conv_xl(const ConvOp &cv) const {
+        return direct_xlds && direct_wlds && dtype == 1 && cv.k == 3 && cv.stride == 2 && cv.cin % 32 == 0 && !cv.up && cv.res_t < 0 && cv.nr == 6 &&
+               cv.kchunks >= 4;
+    }
     // fused BasicBlocks on the 48-channel branch (conv3x3_lds.hip: bbf_run): bit-identical, 2.5x less HBM traffic on that
     // branch, +2.6 % on the whole pass at 256 crops; HRN_BBF=0 goes back to two launches per block
     bool disable_bbf = env_sw("HRN_BBF") && atoi(env_sw("HRN_BBF")) == 0;

@@ -58,6 +58,7 @@ struct ConvArgs {
     int rev;                                // walk the M tiles backwards (see hrn_ctx::alternate)
     int pre_mode;                           // K = 64 1x1 convs with a residual: prefetch variant (1: residual before the K loop, 4-fragment tiles)
     int wlds;                               // bf16, full-size tiles: weights staged through LDS once per block (kernels.hip: WL)
+    int xlds;                               // ... and, for the stride-2 3x3 convolutions with cin % 32 == 0, the pixel fragments through a per-wave LDS ring (kernels.hip: XL)
     // one phase (a, b) of a ConvTranspose2d(4, stride 2, padding 1) run as a 3x3 conv on the input grid: the result of
     // pixel (ho, wo) is stored at (2*ho + a, 2*wo + b) of the twice-as-large tensor (poseresnet.py:84-100)
     int up, up_a, up_b, up_wp, up_hpwp;

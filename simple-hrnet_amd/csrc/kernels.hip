@@ -79,6 +79,70 @@ __device__ __forceinline__ f32x4 mma<DT_F32>(f32x4 w, f32x4 x, f32x4 acc) {
 #define HRN_WL_G 4
 #endif
 constexpr int WL_G = HRN_WL_G;
+// epilogue of the generic kernel: out = [relu](acc + bias [+ residual]), zero on pad pixels, 4*NR contiguous channels per lane
+template <int DT, int NR, int MR, bool PRE>
+__device__ __forceinline__ void conv_direct_epilogue(const ConvArgs &p, const int ng, const int m0, const int li, const int g,
+                                                     f32x4 (&acc)[MR][NR], s16x8 (&rpre)[PRE ? MR : 1][PRE ? NR / 2 : 1]) {
+    using T = Tr<DT>;
+    using elem = typename T::elem;
+    const int ch0 = ng * 16 * NR + g * 4 * NR;
+    float bias[4 * NR];
+#pragma unroll
+    for (int c = 0; c < 4 * NR; ++c) bias[c] = ((const GLOBAL_AS float *)p.bias)[ch0 + c];
+    GLOBAL_AS elem *__restrict__ out = (GLOBAL_AS elem *)p.out;
+    const GLOBAL_AS elem *__restrict__ res = (const GLOBAL_AS elem *)p.res;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int q = m0 + i * 16 + li;
+        if (q >= p.m) continue;
+        const int rem = q % p.out_hpwp;
+        const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
+        const bool ok = (ho < p.out_h) && (wo < p.out_w);
+        size_t o = (size_t)q * p.cout + ch0;
+        if (p.up) {  // transposed-conv phase: scatter to (2*ho + a, 2*wo + b); pad pixels of the phase grid write nothing
+            if (!ok) continue;
+            o = ((size_t)(q / p.out_hpwp) * p.up_hpwp + (size_t)(2 * ho + p.up_a) * p.up_wp + 2 * wo + p.up_b) * p.cout + ch0;
+        }
+        if constexpr (DT == DT_BF16 && (NR % 2 == 0)) {
+            // 8 contiguous channels per access: 16-byte residual loads and stores
+#pragma unroll
+            for (int j = 0; j < NR; j += 2) {
+                s16x8 r8 = {};
+                if constexpr (PRE)
+                    r8 = rpre[i][j / 2];
+                else if (res)
+                    r8 = *(const GLOBAL_AS s16x8 *)(res + o + j * 4);
+                s16x8 o8;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float v = acc[i][j + (r >> 2)][r & 3] + bias[j * 4 + r];
+                    if (PRE || res) v += T::ld((elem)r8[r]);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (!ok) v = 0.f;
+                    o8[r] = (short)T::st(v);
+                }
+                *(GLOBAL_AS s16x8 *)(out + o + j * 4) = o8;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                typename T::out4 r4 = {};
+                if (res) r4 = *(const GLOBAL_AS typename T::out4 *)(res + o + j * 4);
+                typename T::out4 o4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bias[j * 4 + r];
+                    if (res) v += T::ld((elem)r4[r]);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (!ok) v = 0.f;
+                    o4[r] = T::st(v);
+                }
+                *(GLOBAL_AS typename T::out4 *)(out + o + j * 4) = o4;
+            }
+        }
+    }
+}
+
 template <int DT, int NR, int MR, bool PRE = false, bool WL = false>
 __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng, const int mtile_in, char *smem = nullptr) {
     using T = Tr<DT>;
@@ -194,63 +258,115 @@ __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng
         }
     }
 
-    // ---- epilogue: bias (+ residual) (+ ReLU), zero on pad pixels, 4*NR contiguous channels per lane
-    const int ch0 = ng * 16 * NR + g * 4 * NR;
-    float bias[4 * NR];
-#pragma unroll
-    for (int c = 0; c < 4 * NR; ++c) bias[c] = ((const GLOBAL_AS float *)p.bias)[ch0 + c];
-    GLOBAL_AS elem *__restrict__ out = (GLOBAL_AS elem *)p.out;
-    const GLOBAL_AS elem *__restrict__ res = (const GLOBAL_AS elem *)p.res;
+    conv_direct_epilogue<DT, NR, MR, PRE>(p, ng, m0, li, g, acc, rpre);
+}
+
+// XL (round 6): the stride-2 3x3 convolutions with cin % 32 == 0 (96 / 192 / 256 / 384 input channels: 1.5 ms of a 256-crop W48 pass on
+// this kernel at 240-470 TFLOP/s, matrix pipe 19 % busy, waves parked on the L2 round trip of every tap's pixel fragments).  Same tiles,
+// same weight image, same K order and MFMA sequence as conv_direct_body<bf16, NR, 4, false, WL> -- results are bit-identical -- but the
+// pixel fragments of chunk kc + 2 are REQUESTED (LDS-DMA, per-lane source = the lane's 16 bytes of its pixel, lane-linear destination = the
+// fragment image itself) while chunk kc is multiplied: the prefetch buffer is LDS (a private ring of XL_D slots per wave, no barrier), not
+// registers -- the register-ring version cost a wave per SIMD (EXPERIMENTS, round 1).  Weights: XL_G chunks per block-wide stage, double
+// buffered, one barrier per stage.  All waits on vector memory are counted (in order): 8 operations behind a weight stage, 11 behind a
+// chunk's pixels.  LDS: 2 * XL_G * NR KiB + 4 waves * XL_D * 4 KiB = 72 KiB for NR = 6: two blocks per CU.
+constexpr int XL_G = 2, XL_D = 3;
+constexpr int xl_lds_bytes(int nr) { return 2 * XL_G * nr * 1024 + 4 * XL_D * 4 * 1024; }
+__device__ __forceinline__ bool conv_xl_ok(const ConvArgs &p) {
+    return p.stride == 2 && p.ksize == 3 && (p.cin & 31) == 0 && !p.up && !p.res && p.kchunks >= 2 * XL_G;
+}
+__device__ __forceinline__ void xl_glds(const GLOBAL_AS char *base, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(voff), "s"(lds_dst), "s"(base) : "memory", "m0");
+}
+template <int NR>
+__device__ __forceinline__ void conv_direct_xl_body(const ConvArgs &p, const int ng, const int mtile_in, char *smem) {
+    constexpr int MR = 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    if (mtile_in * 64 * MR >= p.m) return;   // (block-uniform: ahead of every barrier)
+    const int mtile = p.rev ? (p.m + 64 * MR - 1) / (64 * MR) - 1 - mtile_in : mtile_in;
+    const int m0 = (mtile * 4 + wave) * (16 * MR);
+    const int cin = p.cin, in_wp = p.in_wp, kchunks = p.kchunks;
+    const int spt = cin >> 5;                       // 32-channel slices (= K chunks) per tap
+    // scalar base = the tensor's row -(in_wp + 1) (the front guard rows: tap (-1, -1) of row 0 is a valid address), per-lane offsets from it
+    const int guard = (in_wp + 1) * cin;
+    const GLOBAL_AS char *const base = (const GLOBAL_AS char *)p.in - (size_t)guard * 2;
+    unsigned xoff[MR];
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
         const int q = m0 + i * 16 + li;
-        if (q >= p.m) continue;
-        const int rem = q % p.out_hpwp;
-        const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
-        const bool ok = (ho < p.out_h) && (wo < p.out_w);
-        size_t o = (size_t)q * p.cout + ch0;
-        if (p.up) {  // transposed-conv phase: scatter to (2*ho + a, 2*wo + b); pad pixels of the phase grid write nothing
-            if (!ok) continue;
-            o = ((size_t)(q / p.out_hpwp) * p.up_hpwp + (size_t)(2 * ho + p.up_a) * p.up_wp + 2 * wo + p.up_b) * p.cout + ch0;
+        int r = 0;   // (rows past the end: any mapped row; masked at the store)
+        if (q < p.m) {
+            const int n = q / p.out_hpwp, rem = q - n * p.out_hpwp;
+            const int ho = rem / p.out_wp, wo = rem - ho * p.out_wp;
+            r = n * p.in_hpwp + 2 * ho * in_wp + 2 * wo;
         }
-        if constexpr (DT == DT_BF16 && (NR % 2 == 0)) {
-            // 8 contiguous channels per access: 16-byte residual loads and stores
-#pragma unroll
-            for (int j = 0; j < NR; j += 2) {
-                s16x8 r8 = {};
-                if constexpr (PRE)
-                    r8 = rpre[i][j / 2];
-                else if (res)
-                    r8 = *(const GLOBAL_AS s16x8 *)(res + o + j * 4);
-                s16x8 o8;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    float v = acc[i][j + (r >> 2)][r & 3] + bias[j * 4 + r];
-                    if (PRE || res) v += T::ld((elem)r8[r]);
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (!ok) v = 0.f;
-                    o8[r] = (short)T::st(v);
-                }
-                *(GLOBAL_AS s16x8 *)(out + o + j * 4) = o8;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                typename T::out4 r4 = {};
-                if (res) r4 = *(const GLOBAL_AS typename T::out4 *)(res + o + j * 4);
-                typename T::out4 o4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bias[j * 4 + r];
-                    if (res) v += T::ld((elem)r4[r]);
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (!ok) v = 0.f;
-                    o4[r] = T::st(v);
-                }
-                *(GLOBAL_AS typename T::out4 *)(out + o + j * 4) = o4;
-            }
-        }
+        xoff[i] = ((unsigned)r * (unsigned)cin + (unsigned)(guard + g * 8)) * 2u;
     }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned xring = lds0 + 2 * XL_G * NR * 1024 + wave * (XL_D * MR * 1024);
+    const GLOBAL_AS char *const wsrc = (const GLOBAL_AS char *)p.w + (size_t)ng * NR * kchunks * 1024;
+    const unsigned lane16 = lane * 16;
+    // pixel fragments of chunk kc -> ring slot kc % XL_D (chunks past the end: the last chunk again, into a slot nobody reads any more --
+    // every wave issues the same number of operations per chunk, which is what the counted waits rely on)
+    auto px_issue = [&](int kc) {
+        const int slot = kc % XL_D;
+        const int kq = kc < kchunks ? kc : kchunks - 1;
+        const int tap = kq / spt, sl = kq - tap * spt;
+        const int dh = (tap * 11) >> 5, dw = tap - dh * 3;
+        const GLOBAL_AS char *sb = base + ((long)((dh - 1) * in_wp + (dw - 1)) * cin + sl * 32) * 2;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) xl_glds(sb, xoff[i], xring + (slot * MR + i) * 1024);
+    };
+    // weight stage gi (chunks gi * XL_G ...) -> buffer gi & 1: NR * XL_G pieces of 1 KiB, three per wave
+    auto w_issue = [&](int gi) {
+#pragma unroll
+        for (int u = 0; u < (NR * XL_G + 3) / 4; ++u) {
+            int t = wave + 4 * u;
+            if (t >= NR * XL_G) t = NR * XL_G - 1;   // (NR * XL_G = 12 = 3 per wave exactly for NR = 6)
+            const int j = t / XL_G;
+            int c = gi * XL_G + (t - j * XL_G);
+            if (c >= kchunks) c = kchunks - 1;
+            xl_glds(wsrc + (size_t)(j * kchunks + c) * 1024, lane16, lds0 + ((gi & 1) * NR * XL_G + t) * 1024);
+        }
+    };
+    static_assert((NR * XL_G) % 4 == 0, "weight pieces per wave");
+    constexpr int WOPS = NR * XL_G / 4;   // 3
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    w_issue(0);
+    px_issue(0);
+    px_issue(1);
+    for (int kc = 0; kc < kchunks; ++kc) {
+        const int gi = kc / XL_G, c = kc - gi * XL_G;
+        if (c == 0) {
+            // this wave's pieces of stage gi have landed (behind them: the pixels of two chunks), then everybody's; everybody is also
+            // done reading the other buffer
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((XL_D - 1) * MR) : "memory");
+            __builtin_amdgcn_s_barrier();
+            w_issue(gi + 1);
+        }
+        px_issue(kc + XL_D - 1);
+        // the pixels of chunk kc: behind them the other XL_D - 2 chunks in flight, a weight stage, and the chunk just requested
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"((XL_D - 1) * MR + WOPS) : "memory");
+        s16x8 a[MR], b[NR];
+        const unsigned xa = xring + (kc % XL_D) * (MR * 1024) + lane16;
+        const unsigned wa = lds0 + ((gi & 1) * NR * XL_G + c) * 1024 + lane16;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[i]) : "v"(xa), "i"(i * 1024));
+#pragma unroll
+        for (int j = 0; j < NR; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[j]) : "v"(wa), "i"(j * XL_G * 1024));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) acc[i][j] = mma<DT_BF16>(b[j], a[i], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the dummy requests past the end: nothing of this block may land in LDS after it)
+    s16x8 rpre[1][1];
+    conv_direct_epilogue<DT_BF16, NR, MR, false>(p, ng, m0, li, g, acc, rpre);
 }
 
 // one convolution per launch.  1-D grid, cout tile fastest: the blocks that share an activation tile are dispatched
@@ -262,6 +378,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
     const int ngroups = p.cout / (16 * NR);
     const int ng = (blockIdx.x >> 3) % ngroups;
     const int mtile = (blockIdx.x / (8 * ngroups)) * 8 + (blockIdx.x & 7);
+    if constexpr (WL && DT == DT_BF16 && NR == 6 && MR == 4 && !PRE) {
+        if (p.xlds && conv_xl_ok(p)) {
+            conv_direct_xl_body<NR>(p, ng, mtile, smem_direct);
+            return;
+        }
+    }
     conv_direct_body<DT, NR, MR, PRE, WL>(p, ng, mtile, smem_direct);
 }
 
@@ -276,7 +398,21 @@ __global__ __launch_bounds__(256) void conv_direct_group_kernel(const ConvArgs *
     const int prob = __builtin_amdgcn_readfirstlane(e.x & 255), ng = __builtin_amdgcn_readfirstlane(e.x >> 8);
     const int mtile = __builtin_amdgcn_readfirstlane(e.y);
     const ConvArgs p = probs[prob];
+    if constexpr (WL && DT == DT_BF16 && NR == 6 && MR == 4) {
+        if (p.xlds && conv_xl_ok(p)) {
+            conv_direct_xl_body<NR>(p, ng, mtile, smem_direct);
+            return;
+        }
+    }
     conv_direct_body<DT, NR, MR, false, WL>(p, ng, mtile, smem_direct);
+}
+
+// dynamic LDS of the WL instantiations: the weight double buffer; wlds == 2 (a launch with XL members): room for the XL layout too
+template <int DT, int NR>
+static constexpr int direct_lds_bytes(int wlds) {
+    const int wl = 2 * WL_G * NR * 1024;
+    if (DT == DT_BF16 && NR == 6 && wlds == 2) return wl > xl_lds_bytes(NR) ? wl : xl_lds_bytes(NR);
+    return wl;
 }
 
 template <int DT, int NR>
@@ -286,7 +422,15 @@ static hipError_t launch_conv_group_t(const ConvArgs *probs, const int2 *map, in
     else if (mr == 2)
         hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 2>), dim3(nblocks), dim3(256), 0, s, probs, map);
     else if (DT == DT_BF16 && wlds)
-        hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 4, DT == DT_BF16>), dim3(nblocks), dim3(256), 2 * WL_G * NR * 1024, s, probs, map);
+    {
+        const int lds = direct_lds_bytes<DT, NR>(wlds);
+        static std::atomic<unsigned long long> lds_set{0};   // (more than 64 KiB of dynamic LDS: per device, kernels.h set_dynamic_lds)
+        if (lds > 65536) {
+            const hipError_t e = set_dynamic_lds((const void *)conv_direct_group_kernel<DT, NR, 4, DT == DT_BF16>, direct_lds_bytes<DT, NR>(2), lds_set);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 4, DT == DT_BF16>), dim3(nblocks), dim3(256), lds, s, probs, map);
+    }
     else
         hipLaunchKernelGGL((conv_direct_group_kernel<DT, NR, 4>), dim3(nblocks), dim3(256), 0, s, probs, map);
     return hipGetLastError();
@@ -335,7 +479,13 @@ static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
         if (a.wlds && a.kchunks >= 2 * WL_G) {
             const int mtiles = (a.m + 255) / 256;
             dim3 grid(((mtiles + 7) / 8) * 8 * (a.cout / (16 * NR)));
-            hipLaunchKernelGGL((conv_direct_kernel<DT, NR, 4, false, true>), grid, dim3(256), 2 * WL_G * NR * 1024, s, a);
+            const int lds = direct_lds_bytes<DT, NR>(a.xlds ? 2 : 1);
+            static std::atomic<unsigned long long> lds_set{0};
+            if (lds > 65536) {
+                const hipError_t e = set_dynamic_lds((const void *)conv_direct_kernel<DT, NR, 4, false, true>, direct_lds_bytes<DT, NR>(2), lds_set);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL((conv_direct_kernel<DT, NR, 4, false, true>), grid, dim3(256), lds, s, a);
             return hipGetLastError();
         }
     return launch_conv_tt<DT, NR, 4, false>(a, s);

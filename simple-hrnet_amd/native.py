@@ -224,6 +224,7 @@ class NativeHRNet:
         copy.wait_stream(compute)
         landed = [torch.cuda.Event(), torch.cuda.Event()]
         consumed = [None, None]
+        norm = [None, None]   # uint8 form: the normalised fp32 crops of each slot
 
         def upload(slot, item):
             images, boxes = item
@@ -235,6 +236,8 @@ class NativeHRNet:
             u8 = images.dtype == torch.uint8
             if u8 and tuple(images.shape[1:]) != (h, w, 3):
                 raise ValueError("uint8 crops must be (n, %d, %d, 3) BGR at the network's resolution" % (h, w))
+            if not u8 and tuple(images.shape[1:]) != (3, h, w):   # (copy_ would broadcast or fail obscurely)
+                raise ValueError("float crops must be (n, 3, %d, %d) at the network's resolution" % (h, w))
             want = (torch.uint8, (self.max_batch, h, w, 3)) if u8 else (torch.float32, (self.max_batch, 3, h, w))
             if stage[slot] is None or stage[slot].dtype != want[0]:
                 # a staging block comes from the caching allocator on the COMPUTE stream and may be recycled memory that kernels already
@@ -259,7 +262,12 @@ class NativeHRNet:
             nxt = next(it, None)
             pending = upload(slot ^ 1, nxt) if nxt is not None else None   # goes out while this batch computes
             compute.wait_event(landed[slot])
-            x = self.resize_frames(stage[slot][:n], 0) if u8 else stage[slot][:n]   # (identity size: colour flip + ToTensor + Normalize)
+            if u8:   # identity size: colour flip + ToTensor + Normalize on the GPU, into ONE fp32 buffer per slot (340 MB at 256 crops)
+                if norm[slot] is None:
+                    norm[slot] = torch.empty((self.max_batch, 3, h, w), dtype=torch.float32, device=dev)
+                x = self.resize_frames(stage[slot][:n], 0, out=norm[slot])
+            else:
+                x = stage[slot][:n]
             out = self.predict_crops(x, boxes, return_heatmaps=return_heatmaps)
             consumed[slot] = torch.cuda.Event()
             consumed[slot].record(compute)
@@ -320,12 +328,13 @@ class NativeHRNet:
             self._check(rc, "hrn_preprocess_frame")
         return images, boxes, boxes_dev
 
-    def resize_frames(self, frames, interpolation: int = 2) -> torch.Tensor:
+    def resize_frames(self, frames, interpolation: int = 2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The single-person pre-path (``multiperson=False``, ``SimpleHRNet.py:213-222`` / ``:355-366``) on the GPU:
         ``cv2.resize(frame, (W, H), interpolation)`` + BGR -> RGB + ToTensor + Normalize for every frame.
 
         ``frames``: (Hf, Wf, 3) or (n, Hf, Wf, 3) uint8 BGR (host arrays are uploaded once); ``interpolation``: the
-        ``cv2.INTER_*`` value -- 0 nearest, 1 linear, 2 cubic (the reference's default).  Returns (n, 3, H, W) float32 on the GPU.
+        ``cv2.INTER_*`` value -- 0 nearest, 1 linear, 2 cubic (the reference's default).  Returns (n, 3, H, W) float32 on the GPU
+        (written into the first n entries of ``out`` when given: ``predict_stream`` keeps one such buffer per staging slot).
         Follows OpenCV's published generic 8-bit path; equality with a particular cv2 build is not pinned (include/hrnet_mi355.h)."""
         if interpolation not in (0, 1, 2):
             raise ValueError("interpolation must be cv2.INTER_NEAREST (0), cv2.INTER_LINEAR (1) or cv2.INTER_CUBIC (2)")
@@ -337,7 +346,13 @@ class NativeHRNet:
             raise ValueError("frames must be (n, H, W, 3) uint8 BGR")
         frames = frames.to(self.torch_device, non_blocking=True).contiguous()
         n, h, w = int(frames.shape[0]), *self.resolution
-        images = torch.empty((n, 3, h, w), dtype=torch.float32, device=self.torch_device)
+        if out is not None:
+            if out.dtype != torch.float32 or out.device != self.torch_device or not out.is_contiguous() or \
+                    out.dim() != 4 or out.shape[0] < n or tuple(out.shape[1:]) != (3, h, w):
+                raise ValueError("out must be a contiguous (>= %d, 3, %d, %d) float32 tensor on %s" % (n, h, w, self.torch_device))
+            images = out[:n]
+        else:
+            images = torch.empty((n, 3, h, w), dtype=torch.float32, device=self.torch_device)
         if n:
             with torch.cuda.device(self.device_index):
                 rc = self._lib.hrn_resize_frames(self._h, frames.data_ptr(), n, int(frames.shape[1]), int(frames.shape[2]),

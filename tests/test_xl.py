@@ -1,0 +1,55 @@
+"""Round 6 (simple-hrnet_amd/csrc/kernels.hip, XL): the stride-2 3x3 convolutions with 96 / 192 / 256 / 384 input channels (reference:
+transition1 / transition2 / transition3 and the fuse-down chains of models_/hrnet.py:36-51, 98-145) request their pixel fragments two
+K chunks ahead by LDS-DMA into a per-wave LDS ring instead of loading every tap's fragments straight from L2.  Same tiles, weight image,
+K order and MFMA sequence as the plain form: with the ring on / off every member convolution and the whole net are BIT-IDENTICAL.  The
+form is only taken by launches large enough for 64-pixel-per-wave tiles, so the cases are full-size calls."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg, state_dict_np
+
+
+def _eligible(infos):
+    return [i for i in infos if i.algo == 0 and i.ksize == 3 and i.stride == 2 and i.cin % 32 == 0 and i.nr == 6 and not i.has_residual]
+
+
+def test_xl_candidates_of_w48():
+    """the plan's stride-2 3x3 convolutions outside the slab kernel are exactly the shapes the XL form is written for (CPU, plan only)"""
+    pkg = load_pkg()
+    net = pkg.NativeHRNet(48, 17, (384, 288), "bf16", max_batch=256, device=-1)
+    infos = net.conv_infos()
+    el = _eligible(infos)
+    shapes = sorted({(i.cin, i.cout) for i in el})
+    assert shapes == [(96, 96), (96, 192), (96, 384), (192, 384), (256, 96)], shapes
+    assert len(el) == 7 + 3 + 2 + 2 + 1
+    # everything else of stride 2 is the slab kernel's (48 input channels) or the 64 -> 64 stem convolution
+    rest = [i for i in infos if i.ksize == 3 and i.stride == 2 and i not in el]
+    assert all(i.cin in (48, 64) for i in rest)
+    net.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,n", [(384, 288, 256), (256, 192, 256), (320, 224, 200)])
+def test_xl_on_off_is_bit_identical(monkeypatch, h, w, n):
+    pkg = load_pkg()
+    g = torch.Generator(device="cuda").manual_seed(91)
+    x = torch.randn((n, 3, h, w), generator=g, device="cuda", dtype=torch.float32)
+    out = {}
+    for tag in ("on", "off"):
+        monkeypatch.delenv("HRN_DIRECT_XLDS", raising=False)
+        if tag == "off":
+            monkeypatch.setenv("HRN_DIRECT_XLDS", "0")
+        net = pkg.NativeHRNet(48, 17, (h, w), "bf16", max_batch=n, device=0).load_state_dict(state_dict_np(48))
+        assert ("HRN_DIRECT_XLDS" in net.switches()) == (tag == "off")
+        out[tag] = net(x).cpu().numpy()
+        names = [i.name.decode() for i in _eligible(net.conv_infos())]
+        taps = {t.name.decode() for t in net.tap_infos()}
+        # the member convolutions themselves (crops from the first, a middle and the last M tiles), before anything downstream could hide a difference
+        out[tag + "_taps"] = {nm: net.forward_tap(x, nm, crop0=0, ncrops=3, crop_step=(n - 1) // 2).cpu().numpy() for nm in names if nm in taps}
+        assert len(out[tag + "_taps"]) >= 10
+        net.close()
+    for t, v in out["on_taps"].items():
+        np.testing.assert_array_equal(v, out["off_taps"][t], err_msg=t)
+    np.testing.assert_array_equal(out["on"], out["off"])
+    assert np.isfinite(out["on"]).all()
