@@ -74,6 +74,7 @@ struct hrn_ctx {
     bool disable_chain = env_sw("HRN_DISABLE_CHAIN") != nullptr;
     bool small_tiles = env_sw("HRN_SMALL_TILES") ? atoi(env_sw("HRN_SMALL_TILES")) != 0 : true;
     int small_below = env_sw("HRN_SMALL_BELOW") ? atoi(env_sw("HRN_SMALL_BELOW")) : 384;
+    int small_keep_above = env_sw("HRN_SMALL_KEEP") ? atoi(env_sw("HRN_SMALL_KEEP")) : 300;   // (0: every convolution of a small launch takes 128-pixel tiles, round 5's rule)
     bool disable_chain_ds = env_sw("HRN_DISABLE_CHAIN_DS") != nullptr;
     // generic conv kernel, bf16: the block's weights through LDS instead of one copy per wave from L2 (+1.6 % on the pass)
     // residual-prefetch variant of the K = 64 1x1 convs; persistent blocks of a chain-kernel launch (read here, at create,
@@ -129,6 +130,11 @@ struct hrn_ctx {
     int long_factor = env_sw("HRN_LONG_FACTOR") ? atoi(env_sw("HRN_LONG_FACTOR")) : 4;
     double long_share = env_sw("HRN_LONG_SHARE") ? atof(env_sw("HRN_LONG_SHARE")) : 0.85;
     int head_slabs = 1, head_slab_px = 1024;
+    static constexpr int kHeadSlabPxSmall = 256;
+    int head_slabs_small = 1;
+    // the head / decode split of a pass of nb crops: 1024-pixel slabs unless that leaves most of the chip idle
+    int head_px_for(int nb) const { return (long)nb * head_slabs >= 192 ? head_slab_px : kHeadSlabPxSmall; }
+    int head_slabs_for(int nb) const { return (long)nb * head_slabs >= 192 ? head_slabs : head_slabs_small; }
     float *part_val = nullptr;
     int *part_idx = nullptr;
     // crop pre-path scratch (grown on demand, never inside hrn_forward)

@@ -215,6 +215,51 @@ __device__ __forceinline__ void conv_direct_body(const ConvArgs &p, const int ng
         }
     };
     if constexpr (WL) stage(0);
+    // round 6, small launches (MR <= 2, bf16): a block's K loop is a chain of L2 round trips -- 27 for a 96 -> 192 stride-2 convolution, 18 us
+    // per launch at 8 crops with the chip mostly idle.  The operands of KU chunks are requested together, then multiplied in the
+    // same order as before (bit-identical): a quarter / half of the round trips.
+    constexpr int KU = (DT == DT_BF16 && !WL && !PRE) ? (MR == 1 ? 4 : MR == 2 ? 2 : 1) : 1;
+    if constexpr (KU > 1) {
+        for (int kc0 = 0; kc0 < p.kchunks; kc0 += KU) {
+            vec b[KU][NR], a[KU][MR];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int kc = kc0 + u;
+                if (kc < p.kchunks) {   // (wave-uniform)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) b[u][j] = *(gvec_p)(wlane + ((size_t)j * p.kchunks + kc) * 1024);
+                    if (tap < ntaps) {
+                        int tapoff = 0;
+                        if (p.ksize == 3) {
+                            const int dh = (tap * 11) >> 5, dw = tap - dh * 3;
+                            tapoff = (dh - 1) * p.in_wp + (dw - 1);
+                        } else if (p.ksize == 2) {
+                            tapoff = tap == 0 ? p.taps[0] : tap == 1 ? p.taps[1] : tap == 2 ? p.taps[2] : p.taps[3];
+                        }
+                        const long aoff = (long)tapoff * p.cin + ci;
+#pragma unroll
+                        for (int i = 0; i < MR; ++i) a[u][i] = *(gvec_p)(in + inrow[i] + aoff);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < MR; ++i) a[u][i] = vec{};
+                    }
+                    ci += T::KC;
+                    while (ci >= p.cin) {
+                        ci -= p.cin;
+                        ++tap;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+                if (kc0 + u < p.kchunks) {
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) acc[i][j] = mma<DT>(b[u][j], a[u][i], acc[i][j]);
+                }
+        }
+    } else
     for (int kc = 0; kc < p.kchunks; ++kc) {
         vec b[NR];
         if constexpr (WL) {

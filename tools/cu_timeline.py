@@ -55,8 +55,9 @@ for s in order:
               seq, len(r), len(cus), span, busy.mean(), 100 * busy.mean() / span, busy.min(), busy.max(), gaps.mean(), first_start.min(), first_start.max(),
               last_end.min(), np.percentile(last_end, 10), np.median(last_end), np.percentile(last_end, 90), last_end.max()))
     # durations by class (rounded to 5 us) with start-time ranges
-    cls = np.round(dur / 5.0) * 5
-    for d in sorted(set(cls))[::-1][:12]:
+    step = float(os.environ.get('STEP', '5'))
+    cls = np.round(dur / step) * step
+    for d in sorted(set(cls))[::-1][:int(os.environ.get('CLASSES', '12'))]:
         m = cls == d
-        print("    blocks of ~%3d us: %4d, started %.1f..%.1f us, ended %.1f..%.1f us" % (d, m.sum(), ((t0[m] - base) / 100.0).min(), ((t0[m] - base) / 100.0).max(),
+        print("    blocks of ~%5.1f us: %4d, started %.1f..%.1f us, ended %.1f..%.1f us" % (d, m.sum(), ((t0[m] - base) / 100.0).min(), ((t0[m] - base) / 100.0).max(),
                                                                                       ((t1[m] - base) / 100.0).min(), ((t1[m] - base) / 100.0).max()))
