@@ -251,7 +251,7 @@ def test_scheduling_variants_are_bit_identical(pkg, dtype, monkeypatch):
     boxes = pkg.synth_boxes(n, seed=22)
 
     def run(env):
-        for k in ("HRN_DISABLE_DGROUP", "HRN_DISABLE_CHAIN", "HRN_DISABLE_CHAIN_DS", "HRN_DISABLE_CHAIN3", "HRN_BBF", "HRN_BBF_MIN_TILES", "HRN_DIRECT_WLDS", "HRN_SMALL_TILES", "HRN_DGROUP_NR", "HRN_ALTERNATE", "HRN_DISABLE_GROUP", "HRN_DISABLE_FGROUP", "HRN_BLOCK_ORDER",
+        for k in ("HRN_DISABLE_DGROUP", "HRN_DISABLE_CHAIN", "HRN_DISABLE_CHAIN_DS", "HRN_DISABLE_CHAIN3", "HRN_BBF", "HRN_BBF_MIN_TILES", "HRN_DIRECT_WLDS", "HRN_DIRECT_XLDS", "HRN_SMALL_KEEP", "HRN_SMALL_TILES", "HRN_DGROUP_NR", "HRN_ALTERNATE", "HRN_DISABLE_GROUP", "HRN_DISABLE_FGROUP", "HRN_BLOCK_ORDER",
                   "HRN_LONG_FACTOR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -263,7 +263,7 @@ def test_scheduling_variants_are_bit_identical(pkg, dtype, monkeypatch):
         return out
 
     base = run({})
-    for env in ({"HRN_DISABLE_DGROUP": "1"}, {"HRN_DISABLE_CHAIN": "1"}, {"HRN_DISABLE_CHAIN_DS": "1"}, {"HRN_DISABLE_CHAIN3": "1"}, {"HRN_BBF": "0"}, {"HRN_BBF_MIN_TILES": "1"}, {"HRN_DIRECT_WLDS": "0"}, {"HRN_SMALL_TILES": "0"}, {"HRN_DGROUP_NR": "0"}, {"HRN_ALTERNATE": "0"}, {"HRN_DISABLE_GROUP": "1"}, {"HRN_DISABLE_FGROUP": "1"},
+    for env in ({"HRN_DISABLE_DGROUP": "1"}, {"HRN_DISABLE_CHAIN": "1"}, {"HRN_DISABLE_CHAIN_DS": "1"}, {"HRN_DISABLE_CHAIN3": "1"}, {"HRN_BBF": "0"}, {"HRN_BBF_MIN_TILES": "1"}, {"HRN_DIRECT_WLDS": "0"}, {"HRN_DIRECT_XLDS": "0"}, {"HRN_SMALL_KEEP": "0"}, {"HRN_SMALL_TILES": "0"}, {"HRN_DGROUP_NR": "0"}, {"HRN_ALTERNATE": "0"}, {"HRN_DISABLE_GROUP": "1"}, {"HRN_DISABLE_FGROUP": "1"},
                 {"HRN_BLOCK_ORDER": "0", "HRN_LONG_FACTOR": "1"}):
         hm, pts = run(env)
         np.testing.assert_array_equal(hm, base[0], err_msg=str(env))

@@ -189,7 +189,7 @@ def test_block_maps_cover_every_tile_at_other_resolutions(res, n, monkeypatch):
     net.close()
 
 
-@pytest.mark.parametrize("n", [1, 3, 20, 64, 96, 200, 256])
+@pytest.mark.parametrize("n", [1, 3, 8, 12, 20, 64, 96, 200, 256])   # (8, 12: small launches in which the short convolutions keep full tiles, round 6)
 @pytest.mark.parametrize("reverse", [0, 1])
 def test_block_maps_cover_every_tile_exactly_once(n, reverse):
     """The block maps of the grouped BasicBlock launches (hrnet_mi355.cpp: group_blocks) for W48 384x288: whatever the

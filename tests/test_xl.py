@@ -53,3 +53,32 @@ def test_xl_on_off_is_bit_identical(monkeypatch, h, w, n):
         np.testing.assert_array_equal(v, out["off_taps"][t], err_msg=t)
     np.testing.assert_array_equal(out["on"], out["off"])
     assert np.isfinite(out["on"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [8, 12])
+def test_small_launch_tile_rule_is_bit_identical(monkeypatch, n):
+    """Round 6 (ctx_memory.inc: group_blocks): in a small launch the short convolutions (the 48-channel branch: two half-stages per tile) keep
+    full tiles when 128-pixel tiles would make more than ~1.2 blocks per CU; the (48, 3) form's arithmetic does not depend on the tile size, so
+    HRN_SMALL_KEEP=0 (every convolution on 128-pixel tiles, round 5's rule) gives the same bits -- as does the 256-pixel head split of small calls
+    against the reference decode (tests/test_gpu_parity.py) and a 256-crop call that contains the same crops."""
+    pkg = load_pkg()
+    h, w = 384, 288
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = torch.randn((64, 3, h, w), generator=g, device="cuda", dtype=torch.float32)
+    boxes = pkg.synth_boxes(64, seed=5)
+    out = {}
+    for tag in ("keep", "small"):
+        monkeypatch.delenv("HRN_SMALL_KEEP", raising=False)
+        if tag == "small":
+            monkeypatch.setenv("HRN_SMALL_KEEP", "0")
+        net = pkg.NativeHRNet(48, 17, (h, w), "bf16", max_batch=64, device=0).load_state_dict(state_dict_np(48))
+        hm, pts = net.predict_crops(x[:n].contiguous(), boxes[:n], return_heatmaps=True)
+        out[tag] = (hm.cpu().numpy(), pts.cpu().numpy())
+        if tag == "keep":   # the same crops inside a 64-crop call (1024-pixel head slabs, full tiles everywhere)
+            hm64, pts64 = net.predict_crops(x, boxes, return_heatmaps=True)
+            out["big"] = (hm64[:n].cpu().numpy(), pts64[:n].cpu().numpy())
+        net.close()
+    for other in ("small", "big"):
+        np.testing.assert_array_equal(out["keep"][0], out[other][0], err_msg=other)
+        np.testing.assert_array_equal(out["keep"][1], out[other][1], err_msg=other)

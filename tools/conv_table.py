@@ -27,6 +27,8 @@ ALGO = {0: "generic", 1: "lds", 2: "fused-bb", 3: "n96", 4: "slab"}
 groups = defaultdict(lambda: [0, 0.0, 0.0])
 rows = []
 for i, ci in enumerate(infos):
+    if ci.name == b"conv2" and net.stem_fused():
+        continue   # runs inside stem_fused_kernel (listed under "other": stem); its slot in the per-conv times is an empty launch
     fl = 2.0 * ci.cout * ci.cin * ci.ksize * ci.ksize * ci.out_h * ci.out_w * n
     key = (ALGO.get(ci.algo, str(ci.algo)), "%dx%d s%d" % (ci.ksize, ci.ksize, ci.stride), ci.cin, ci.cout, ci.out_h)
     g = groups[key]
