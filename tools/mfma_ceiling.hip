@@ -33,7 +33,9 @@ constexpr int WP = 37;   // the 48x36 grid
 // PITCH (round 6): 0 = every vector-memory instruction moves one contiguous KiB (round 5's streams); > 0 = the kernel's real access
 //       shape on an NHWC tensor whose pixel rows are PITCH bytes apart -- an LDS-DMA slab piece is 16 pixel rows x 64 bytes (one
 //       32-channel slice, slice after slice of the same rows), a residual load / store 16 pixel rows x 64 bytes
-template <int V, int ABL = 0, int LDM = 0, int STM = 0, int PITCH = 0>
+// WFOOT (round 6): 0 = the weight pieces of every stage come from the same 24 KiB of the block (round 5: L1 / L2-hot); N > 0 = they walk through N stages' worth
+//       of weights (24 KiB each) shared by all blocks with the same blockIdx & 3, as the kernel's cout tiles are (27 stages = the 663 KiB of a 384-channel cout tile)
+template <int V, int ABL = 0, int LDM = 0, int STM = 0, int PITCH = 0, int WFOOT = 0>
 __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *stamps, int stages, const unsigned *init, const char *src, char *big) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,6 +182,8 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(float *out, long long *s
                             if (gi % 3 == 1) {   // six slots: three weight pieces, three slab pieces
                                 const unsigned dst = sl < 3 ? wdst + sl * 8192 : sdst + (sl - 3) * 8192;
                                 const GLOBAL_AS char *sp = gsrc + sl * 8192;
+                                if (WFOOT && sl < 3)
+                                    sp = (const GLOBAL_AS char *)src + (size_t)(blockIdx.x & 3) * (WFOOT * 24576) + (size_t)(q % WFOOT) * 24576 + sl * 8192 + wave * 1024;
                                 if (V >= 4 && sl >= 3) sp = bigb + bpos + (sl - 3) * 8192;
                                 unsigned vo = lane16;
                                 if (PITCH && V >= 4 && sl >= 3) {   // piece (P, sl - 3) of this slice's slab: 128 rows further per piece
@@ -289,20 +293,20 @@ static unsigned *g_init[2];
 static char *g_src[2];
 static char *g_big;
 static int g_blocks = 256;
-template <int V, int ABL = 0, int LDM = 0, int STM = 0, int PITCH = 0>
+template <int V, int ABL = 0, int LDM = 0, int STM = 0, int PITCH = 0, int WFOOT = 0>
 static void run(const char *name, int fill) {
     float *d; hipMalloc(&d, 256 * 512 * 4);
     long long *st; hipMalloc(&st, 256 * 16);
-    hipFuncSetAttribute((const void *)stream_kernel<V, ABL, LDM, STM, PITCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    hipFuncSetAttribute((const void *)stream_kernel<V, ABL, LDM, STM, PITCH, WFOOT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     const int stages = 9000, blocks = g_blocks;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    stream_kernel<V, ABL, LDM, STM, PITCH><<<blocks, 512, LDSB>>>(d, st, 60, g_init[fill], g_src[fill], g_big);
+    stream_kernel<V, ABL, LDM, STM, PITCH, WFOOT><<<blocks, 512, LDSB>>>(d, st, 60, g_init[fill], g_src[fill], g_big);
     hipDeviceSynchronize();
     float best = 1e30f;
     double ticks = 0, mhz = 0;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        stream_kernel<V, ABL, LDM, STM, PITCH><<<blocks, 512, LDSB>>>(d, st, stages, g_init[fill], g_src[fill], g_big);
+        stream_kernel<V, ABL, LDM, STM, PITCH, WFOOT><<<blocks, 512, LDSB>>>(d, st, stages, g_init[fill], g_src[fill], g_big);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) {
@@ -344,6 +348,19 @@ int main(int argc, char **argv) {
     }
     hipMalloc(&g_big, (size_t)256 * (8u << 20));
     hipMemset(g_big, 0x3c, (size_t)256 * (8u << 20));
+    if (mode == 2) {   // round 6: weights streamed through a realistic footprint
+        for (int rep = 0; rep < 2; ++rep)
+            for (int fill = 0; fill < 2; ++fill) {
+                run<3>("D  stage loop + barrier + 6 LDS-DMA pieces, the same 24 KiB of weights every stage", fill);
+                run<3, 0, 0, 0, 0, 27>("Dw27  weights walk 27 stages (663 KiB per cout tile, 4 tiles)", fill);
+                run<3, 0, 0, 0, 0, 7>("Dw7  weights walk 7 stages (172 KiB per cout tile)", fill);
+                run<4>("H  D, slab pieces from HBM", fill);
+                run<4, 0, 0, 0, 0, 27>("Hw27  H with weights walking 27 stages", fill);
+                run<4, 0, 0, 0, 192, 27>("H192w27  strided slab pieces + walking weights", fill);
+                run<5, 0, 0, 0, 192, 27>("T192w27  + residual loads, epilogue, stores", fill);
+            }
+        return 0;
+    }
     if (mode == 1) {
         for (int rep = 0; rep < 2; ++rep)
             for (int fill = 0; fill < 2; ++fill) {
