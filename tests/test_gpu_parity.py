@@ -445,4 +445,13 @@ def test_predict_stream_hides_uploads_and_matches_predict_crops(pkg):
         np.testing.assert_array_equal(g, r)
     with pytest.raises(ValueError):
         list(net.predict_stream([(torch.zeros((2, h, w + 1, 3), dtype=torch.uint8), pkg.synth_boxes(2))]))
+    with pytest.raises(ValueError):   #  a wrong-shaped fp32 batch is refused by name, not by a broadcast error inside copy_
+        list(net.predict_stream([(torch.zeros((2, 3, h, w + 1)), pkg.synth_boxes(2))]))
+    # the uint8 form normalises into ONE fp32 buffer per staging slot (resize_frames(out=...)): a caller-supplied buffer is validated
+    buf = torch.empty((4, 3, h, w), dtype=torch.float32, device="cuda")
+    u8 = torch.randint(0, 256, (3, h, w, 3), dtype=torch.uint8)
+    a = net.resize_frames(u8, 0, out=buf)
+    assert a.data_ptr() == buf.data_ptr() and torch.equal(a, net.resize_frames(u8, 0))
+    with pytest.raises(ValueError):
+        net.resize_frames(u8, 0, out=torch.empty((2, 3, h, w), dtype=torch.float32, device="cuda"))
     net.close()

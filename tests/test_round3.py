@@ -68,6 +68,24 @@ def test_local_rank_beyond_the_visible_gpus_is_a_launch_error(monkeypatch):
         sh.resolve_devices("cuda")
 
 
+def test_explicit_device_lists_map_the_local_rank_with_a_modulo(monkeypatch):
+    """the range check applies only where LOCAL_RANK IS the device index (None / 'cuda' / torch.device('cuda')).  A launch in
+    which every rank sees one GPU (its own CUDA_VISIBLE_DEVICES) and names it 'cuda:0', or two ranks that share one GPU via 'cuda:0,0',
+    resolves through ids[local_rank % len(ids)] as before."""
+    sh = load_pkg("simple_hrnet")
+    for k in _LAUNCH_VARS:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert sh.resolve_devices("cuda:0") == [0]
+    assert sh.resolve_devices("cuda:0,0") == [0]
+    assert sh.resolve_devices(torch.device("cuda", 0)) == [0]
+    for direct in (None, "cuda", torch.device("cuda")):
+        with pytest.raises(ValueError, match="LOCAL_RANK=1"):
+            sh.resolve_devices(direct)
+
+
 def test_rank_and_world_size_without_a_local_rank(monkeypatch):
     sh = load_pkg("simple_hrnet")
     for k in _LAUNCH_VARS:
