@@ -7,7 +7,7 @@ import torch
 pkg = importlib.import_module("simple-hrnet_amd")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 bad = 0
-for c, h, w, dtype, n, mb in ((48, 384, 288, "bf16", 256, 256), (48, 384, 288, "bf16", 77, 256), (32, 256, 192, "bf16", 256, 256),
+for c, h, w, dtype, n, mb in ((48, 384, 288, "bf16", 256, 256), (48, 384, 288, "bf16", 77, 256), (48, 384, 288, "bf16", 8, 8), (32, 256, 192, "bf16", 256, 256),
                               (32, 256, 192, "fp32", 64, 64), (48, 256, 192, "fp32", 40, 32)):
     net = pkg.NativeHRNet(c, 17, (h, w), dtype, max_batch=mb, device=0).load_state_dict(pkg.synth_state_dict(c, 17, 0))
     g = torch.Generator(device="cuda").manual_seed(9)
