@@ -30,8 +30,9 @@ def test_xl_candidates_of_w48():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("h,w,n", [(384, 288, 256), (256, 192, 256), (320, 224, 200)])
-def test_xl_on_off_is_bit_identical(monkeypatch, h, w, n):
+@pytest.mark.parametrize("c,h,w,n", [(48, 384, 288, 256), (48, 256, 192, 256), (48, 320, 224, 200), (96, 192, 160, 192)])
+def test_xl_on_off_is_bit_identical(monkeypatch, c, h, w, n):
+    """(c = 96: a net whose every branch width is a multiple of 96 -- input channels 96 / 192 / 384 / 768 all take the form)"""
     pkg = load_pkg()
     g = torch.Generator(device="cuda").manual_seed(91)
     x = torch.randn((n, 3, h, w), generator=g, device="cuda", dtype=torch.float32)
@@ -40,7 +41,7 @@ def test_xl_on_off_is_bit_identical(monkeypatch, h, w, n):
         monkeypatch.delenv("HRN_DIRECT_XLDS", raising=False)
         if tag == "off":
             monkeypatch.setenv("HRN_DIRECT_XLDS", "0")
-        net = pkg.NativeHRNet(48, 17, (h, w), "bf16", max_batch=n, device=0).load_state_dict(state_dict_np(48))
+        net = pkg.NativeHRNet(c, 17, (h, w), "bf16", max_batch=n, device=0).load_state_dict(state_dict_np(c))
         assert ("HRN_DIRECT_XLDS" in net.switches()) == (tag == "off")
         out[tag] = net(x).cpu().numpy()
         names = [i.name.decode() for i in _eligible(net.conv_infos())]
